@@ -1,0 +1,181 @@
+/*
+ * rt_hip.h - C ABI of the MI355X (gfx950) ray-tracing library.
+ *
+ * This library replaces ONE path of pxk5958/ray-tracer: everything that sits behind the
+ * JavaScript class `RayTracer` (reference js/8-kd_tree.js:2298-2589) - the k-d tree build,
+ * the per-pixel Whitted ray loop that the reference runs as a generated GLSL fragment
+ * shader (js/8-kd_tree.js:196-1071), the log-average-luminance reduction
+ * (js/8-kd_tree.js:2558-2569) and the tone-reproduction present pass (js/8-kd_tree.js:85-143).
+ *
+ * Conventions
+ *   - every entry point returns 0 on success and a negative value on failure;
+ *     rt_last_error() returns the message of the last failure on that context
+ *     (or of the last failed rt_create when ctx is NULL).
+ *   - the library copies every input during the call; output buffers are caller-owned.
+ *   - one caller thread per context.
+ *   - matrices are 16 floats, column-major, exactly the order of THREE.Matrix4.toArray()
+ *     as handed to gl.uniformMatrix4fv (js/8-kd_tree.js:1118-1120).
+ *   - image rows are bottom-up, like gl.readPixels (js/8-kd_tree.js:2558).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+/* primitive kinds: the five analytic classes of js/8-kd_tree.js:1267-1537 */
+enum { RT_PRIM_PLANE = 0, RT_PRIM_RECT = 1, RT_PRIM_SPHERE = 2, RT_PRIM_CUBE = 3, RT_PRIM_CYLINDER = 4 };
+/* material types: Material.PHONG_MATERIAL.. (js/8-kd_tree.js:2124-2134) */
+enum { RT_MAT_PHONG = 0, RT_MAT_PHONG_BLINN = 1, RT_MAT_PHONG_CHECKERED = 2 };
+/* k-d node types in the top two metadata bits (js/8-kd_tree.js:1540-1567) */
+enum { RT_KD_INVALID = 0, RT_KD_INTERNAL = 1, RT_KD_EMPTY_LEAF = 2, RT_KD_LEAF = 3 };
+
+/* The reference is configured by the constants at the top of its script
+ * (js/8-kd_tree.js:25-46) plus the canvas size (8-kd_tree.html:11). */
+typedef struct rt_config {
+    int32_t width;               /* canvas WIDTH  */
+    int32_t height;              /* canvas HEIGHT */
+    int32_t supersampling;       /* SUPERSAMPLING: the tracer renders width*S x height*S */
+    int32_t max_depth;           /* MAX_RECURSION_DEPTH: ray tree has 2^D - 1 slots */
+    int32_t tr_method;           /* TONE_REPRODUCTION_METHOD: 0 Ward, 1 Reinhard */
+    int32_t render_triangles;    /* RENDER_TRIANGLES */
+    int32_t use_kd_tree;         /* USE_KD_TREE (0 = brute force over all faces) */
+    int32_t max_kd_depth;        /* MAX_KD_TREE_DEPTH (<= 24) */
+    float   L_max;               /* L_MAX  = 1000 */
+    float   L_dmax;              /* L_DMAX = 500  */
+    float   A;                   /* A = 0.18 (Reinhard key) */
+    float   infinity;            /* INFINITY = 100000.0 (100000.1 in 6-transmission.js:22) */
+    float   epsilon;             /* EPSILON = 1e-4 */
+    float   sphere_epsilon;      /* SPHERE_EPSILON = 0.095 */
+    float   plane_rect_epsilon;  /* PLANE_RECT_EPSILON = 0.095 */
+    float   triangle_epsilon;    /* TRIANGLE_EPSILON = 1e-4 */
+    /* multi-GPU sharding of the image: this context renders the 8x8-pixel tiles whose
+     * index (row-major over tiles) is congruent to shard_index modulo shard_count.
+     * shard_count <= 1 renders the whole frame. No counterpart in the reference. */
+    int32_t shard_index;
+    int32_t shard_count;
+    int32_t device;              /* HIP device ordinal */
+    int32_t reserved;
+} rt_config;
+
+/* One analytic primitive = the two mat4 uniforms `model<i>` / `invModel<i>` plus the
+ * material constants baked into the generated GLSL (js/8-kd_tree.js:1195-1231).
+ * Order in the array is scene order: ties are resolved by the strict `hitInfo.t < tMin`
+ * of js/8-kd_tree.js:1204, i.e. the earlier primitive wins. */
+typedef struct rt_prim {
+    int32_t kind;
+    int32_t mat_type;
+    int32_t mat_id;
+    int32_t reserved;
+    float   model[16];
+    float   inv_model[16];
+} rt_prim;
+
+/* One entry of phongMaterials[] / phongBlinnMaterials[] / phongCheckeredMaterials[]
+ * (js/8-kd_tree.js:255-281). (type, id) select the uniform array and the slot in it.
+ * Co is Co1 for the checkered material; Co2 is used only by it. */
+typedef struct rt_material {
+    int32_t type;
+    int32_t id;
+    float   ka, kd, ks, ke, kReflect, kRefract, ior;
+    float   Co[3];
+    float   Co2[3];
+    float   Cs[3];
+} rt_material;
+
+/* pointLights[i] (js/8-kd_tree.js:284-288) */
+typedef struct rt_light {
+    float position[3];
+    float color[3];
+} rt_light;
+
+/* counters of the last rt_trace (this context's shard only) */
+typedef struct rt_stats {
+    uint64_t rays_total;        /* valid ray-tree nodes: primary + reflected + refracted */
+    uint64_t rays_per_level[8]; /* the same, split by ray-tree level */
+    uint64_t shadow_rays;       /* lights x shaded nodes */
+    uint64_t pixels;            /* pixels of this shard (supersampled resolution) */
+    double   trace_ms;          /* device time of the whole trace (all levels + composite) */
+    double   level_kernel_ms[8];/* device time of the per-level trace kernel */
+    double   composite_ms;      /* device time of the bottom-up colour accumulation */
+    double   tone_ms;           /* device time of the last rt_tone reduction */
+    double   kd_build_ms;       /* host time of the last rt_build_kdtree */
+    double   kd_upload_ms;      /* host->device copy of the compact tree */
+} rt_stats;
+
+/* ---- life cycle ------------------------------------------------------------------ */
+/* replaces `new RayTracer()` (js/8-kd_tree.js:2299-2345): allocates the render target */
+int rt_create(const rt_config *cfg, rt_ctx **out_ctx);
+void rt_destroy(rt_ctx *ctx);
+const char *rt_last_error(const rt_ctx *ctx);
+/* rt_config filled with the constants of js/8-kd_tree.js:25-46 and a 640x480 canvas */
+void rt_default_config(rt_config *cfg);
+
+/* ---- scene: replaces the uniform marshalling of RayTracer.update (js/8-kd_tree.js:2435-2453,
+ *      :1104-1126) and the shader regeneration of RayTracer.setScene (:2347-2431) -------- */
+int rt_set_primitives(rt_ctx *ctx, const rt_prim *prims, int32_t n);
+int rt_set_materials(rt_ctx *ctx, const rt_material *mats, int32_t n);
+/* n_loop is the trip count of the light loop baked into the shader (`nextPointLightId`,
+ * js/8-kd_tree.js:787); lights beyond n keep zero position and colour, as uniforms that
+ * were never set do. Pass n_loop = n when every light is set. */
+int rt_set_lights(rt_ctx *ctx, const rt_light *lights, int32_t n, int32_t n_loop);
+int rt_set_globals(rt_ctx *ctx, const float ambient[3], const float bg_color[3]);
+/* cameraPos and the four corner rays of getPrimaryRay (js/8-kd_tree.js:1094-1098,:2448-2452) */
+int rt_set_camera(rt_ctx *ctx, const float pos[3], const float ray00[3], const float ray01[3],
+                  const float ray10[3], const float ray11[3]);
+
+/* ---- mesh + k-d tree: replaces the per-frame vertsData/facesData fill (js/8-kd_tree.js:2461-2484)
+ *      and `new KdTree().buildTree(...)` + fillDataArray + leaf copy (:2497-2520) ---------- */
+/* verts: n_verts*3 doubles = g_verts as the builder sees them (f64); the device copy is
+ * narrowed to f32 exactly like `vertsData[i*3+0] = g_verts[i].x` (:2462-2464).
+ * faces: n_faces*3 vertex indices; face_mat: n_faces*2 = (material type, material id). */
+int rt_set_mesh(rt_ctx *ctx, const double *verts, int32_t n_verts, const uint32_t *faces,
+                const uint32_t *face_mat, int32_t n_faces);
+/* builds the median-split tree over all faces and uploads the compact device layout */
+int rt_build_kdtree(rt_ctx *ctx);
+/* sizes of the canonical (reference-layout) export */
+int rt_kdtree_counts(rt_ctx *ctx, int64_t *n_nodes, int64_t *n_leaves);
+/* canonical export for the bit-exact check: `nodes` receives n_nodes (heapIndex, metadata)
+ * pairs in ascending heap index = the non-zero entries of kdTreeData (js/8-kd_tree.js:1632-1645);
+ * `leaves` receives n_leaves*4 face indices = kdLeavesData (:2504-2508); root_box = root.min, root.max */
+int rt_export_kdtree_reference(rt_ctx *ctx, uint32_t *nodes, int32_t *leaves, double root_box[6]);
+
+/* ---- frame: replaces the tracer draw call (js/8-kd_tree.js:2550-2555) -------------------- */
+int rt_trace(rt_ctx *ctx);
+/* float colour before clamping, 3 floats per pixel, width*S x height*S, bottom-up rows.
+ * Pixels outside this context's shard are left untouched. */
+int rt_read_float(rt_ctx *ctx, float *rgb);
+/* = gl.readPixels(RGBA, UNSIGNED_BYTE) of the render target (js/8-kd_tree.js:2558) */
+int rt_read_rgba8(rt_ctx *ctx, uint8_t *rgba);
+/* primary hit ids, one int32 per pixel: -1 miss, 0..n_prims-1 analytic primitive,
+ * n_prims + face index for a mesh triangle */
+int rt_read_hit_ids(rt_ctx *ctx, int32_t *ids);
+
+/* ---- tone reproduction: replaces the CPU loop of js/8-kd_tree.js:2559-2569 --------------- */
+/* partial sums over this shard: sum of log(EPSILON + L) and pixel count; the multi-GPU
+ * caller adds them across ranks (all-reduce) before rt_tone_finish */
+int rt_tone_partial(rt_ctx *ctx, double *sum_log, uint64_t *count);
+/* Lbar = exp(sum_log / count), sf = Ward scale factor; stored in the context for rt_present */
+int rt_tone_finish(rt_ctx *ctx, double sum_log, uint64_t count, double *Lbar, double *sf);
+/* single-GPU convenience: rt_tone_partial + rt_tone_finish */
+int rt_tone(rt_ctx *ctx, double *Lbar, double *sf);
+/* present pass (js/8-kd_tree.js:85-143): SxS box filter, tone operator, canvas RGBA8 */
+int rt_present(rt_ctx *ctx, uint8_t *canvas_rgba);
+
+/* ---- device-resident access for multi-GPU gathers (no host round trip) ------------------- */
+/* device pointer of the RGBA8 render target (width*S*height*S*4 bytes) */
+int rt_device_rgba8(rt_ctx *ctx, void **dptr, size_t *bytes);
+int rt_device_float(rt_ctx *ctx, void **dptr, size_t *bytes);
+
+int rt_get_stats(rt_ctx *ctx, rt_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */
