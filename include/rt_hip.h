@@ -60,7 +60,8 @@ typedef struct rt_config {
      * shard_count <= 1 renders the whole frame. No counterpart in the reference. */
     int32_t shard_index;
     int32_t shard_count;
-    int32_t device;              /* HIP device ordinal */
+    int32_t device;              /* HIP device ordinal; -1 = host-only context (mesh, k-d build and
+                                    export work, every entry point that needs a GPU fails) */
     int32_t reserved;
 } rt_config;
 
@@ -172,6 +173,15 @@ int rt_present(rt_ctx *ctx, uint8_t *canvas_rgba);
 /* device pointer of the RGBA8 render target (width*S*height*S*4 bytes) */
 int rt_device_rgba8(rt_ctx *ctx, void **dptr, size_t *bytes);
 int rt_device_float(rt_ctx *ctx, void **dptr, size_t *bytes);
+/* this context's shard of the RGBA8 target in compact tile order: [tile of the shard][64 pixels of the
+ * 8x8 tile, row-major][4 bytes]; alpha 0 marks lanes of edge tiles that fall outside the image.
+ * bytes = 256 * (number of tiles of the shard). */
+int rt_device_shard_rgba8(rt_ctx *ctx, void **dptr, size_t *bytes);
+/* root side of the framebuffer gather: `gathered` (device memory of this context's device) holds
+ * n_shards compact shard buffers back to back, each padded to stride_bytes (a multiple of 256);
+ * scatters them into this context's full-frame RGBA8 target so that rt_read_rgba8 / rt_present see
+ * the whole image. Replaces nothing in the reference (single GPU there). */
+int rt_assemble_shards(rt_ctx *ctx, const void *gathered, size_t stride_bytes, int32_t n_shards);
 
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 

@@ -1,0 +1,285 @@
+// See kd_build.h. Reference: KdTree.buildTree / faceBoxOverlap / axisTest_* / planeBoxOverlap,
+// js/8-kd_tree.js:1647-1970.
+#include "kd_build.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <thread>
+#include <utility>
+
+namespace rt {
+namespace {
+
+struct BoxD { double lo[3], hi[3]; };
+struct BoxF { float lo[3], hi[3]; };
+struct MeshRef { const double *v; const uint32_t *f; };
+
+// One separating-axis test of the reference's axisTest_* family (js/8-kd_tree.js:1829-1929):
+// projections pa/pb of two vertices against the box radius on that axis.
+static inline bool separated(double pa, double pb, double rad) {
+    return pa < pb ? (pa > rad || pb < -rad) : (pb > rad || pa < -rad);
+}
+
+// Triangle/box overlap exactly as js/8-kd_tree.js:1737-1827 evaluates it. P = vertices relative to the
+// box centre, H = half extents. The reference forms the normal with Vector3.cross(), which in r84
+// overwrites its receiver: after js/8-kd_tree.js:1760 the "first edge" is the normal, and the first three
+// axis tests (js/8-kd_tree.js:1762-1773) use the normal's components. Kept as is - it decides which faces
+// each child receives.
+static bool tri_box_overlap(const MeshRef &m, const BoxD &b, uint32_t face) {
+    double H[3], Cn[3], P[3][3];
+    for (int k = 0; k < 3; k++) {
+        Cn[k] = (b.lo[k] + b.hi[k]) * 0.5;
+        H[k] = std::fabs(b.hi[k] - b.lo[k]) * 0.5;
+    }
+    for (int i = 0; i < 3; i++) {
+        const double *s = m.v + 3 * (size_t)m.f[3 * (size_t)face + i];
+        for (int k = 0; k < 3; k++) P[i][k] = s[k] - Cn[k];
+    }
+    double E1[3], E2[3], N[3];
+    {
+        double E0[3];
+        for (int k = 0; k < 3; k++) {
+            E0[k] = P[1][k] - P[0][k];
+            E1[k] = P[2][k] - P[1][k];
+            E2[k] = P[0][k] - P[2][k];
+        }
+        N[0] = E0[1] * E1[2] - E0[2] * E1[1];
+        N[1] = E0[2] * E1[0] - E0[0] * E1[2];
+        N[2] = E0[0] * E1[1] - E0[1] * E1[0];
+    }
+    // projection helpers: X-type uses (y,z), Y-type (x,z) with the reference's signs, Z-type (x,y)
+    auto px = [&](const double *e, int i) { return e[2] * P[i][1] - e[1] * P[i][2]; };
+    auto py = [&](const double *e, int i) { return -e[2] * P[i][0] + e[0] * P[i][2]; };
+    auto pz = [&](const double *e, int i) { return e[1] * P[i][0] - e[0] * P[i][1]; };
+    auto rx = [&](const double *e) { return std::fabs(e[2]) * H[1] + std::fabs(e[1]) * H[2]; };
+    auto ry = [&](const double *e) { return std::fabs(e[2]) * H[0] + std::fabs(e[0]) * H[2]; };
+    auto rz = [&](const double *e) { return std::fabs(e[1]) * H[0] + std::fabs(e[0]) * H[1]; };
+
+    // "edge 0" = the normal: X01, Y02, Z12
+    if (separated(px(N, 0), px(N, 2), rx(N))) return false;
+    if (separated(py(N, 0), py(N, 2), ry(N))) return false;
+    if (separated(pz(N, 1), pz(N, 2), rz(N))) return false;
+    // edge 1: X01, Y02, Z0
+    if (separated(px(E1, 0), px(E1, 2), rx(E1))) return false;
+    if (separated(py(E1, 0), py(E1, 2), ry(E1))) return false;
+    if (separated(pz(E1, 0), pz(E1, 1), rz(E1))) return false;
+    // edge 2: X2, Y1, Z12
+    if (separated(px(E2, 0), px(E2, 1), rx(E2))) return false;
+    if (separated(py(E2, 0), py(E2, 1), ry(E2))) return false;
+    if (separated(pz(E2, 1), pz(E2, 2), rz(E2))) return false;
+
+    for (int k = 0; k < 3; k++) {
+        double mn = std::fmin(P[0][k], std::fmin(P[1][k], P[2][k]));
+        double mx = std::fmax(P[0][k], std::fmax(P[1][k], P[2][k]));
+        if (mn > H[k] || mx < -H[k]) return false;
+    }
+    // planeBoxOverlap(normal, vert0, halfsize), js/8-kd_tree.js:1931-1970
+    double vmin[3], vmax[3];
+    for (int k = 0; k < 3; k++) {
+        double v = P[0][k];
+        if (N[k] > 0) { vmin[k] = -H[k] - v; vmax[k] = H[k] - v; }
+        else { vmin[k] = H[k] - v; vmax[k] = -H[k] - v; }
+    }
+    if (N[0] * vmin[0] + N[1] * vmin[1] + N[2] * vmin[2] > 0) return false;
+    return N[0] * vmax[0] + N[1] * vmax[1] + N[2] * vmax[2] >= 0;
+}
+
+constexpr uint32_t T_INTERNAL = 1u << 30, T_EMPTY = 2u << 30, T_LEAF = 3u << 30;
+
+struct Arena {
+    std::vector<KdNodeDev> nodes;
+    std::vector<uint32_t> heap;
+    std::vector<KdLeafDev> leaves;
+    int depth = 0;
+    int64_t n_internal = 0, n_leaf = 0, n_empty = 0;
+};
+
+struct Task {
+    uint32_t top_slot;  // slot of the subtree root in the top arena
+    uint32_t heap;
+    int depth;
+    BoxD bd;
+    BoxF bf;
+    std::vector<uint32_t> faces;
+    Arena arena;        // nodes[0] = subtree root, then child pairs
+};
+
+struct Builder {
+    MeshRef mesh;
+    int max_depth;
+    int split_depth;            // subtrees rooted at this depth become tasks (0 = never)
+    std::vector<Task> *tasks;   // only the top pass appends
+    // DFS (upper child first) event order of the top pass: >= 0 top-arena leaf number, < 0 task ~id
+    std::vector<int64_t> *events;
+
+    void node(Arena &A, uint32_t slot, uint32_t heap, int depth, const BoxD &bd, const BoxF &bf,
+              std::vector<uint32_t> faces, bool top) {
+        A.heap[slot] = heap;
+        if (depth > A.depth) A.depth = depth;
+        if (faces.size() > 4 && depth < max_depth) {
+            if (top && split_depth > 0 && depth == split_depth) {
+                events->push_back(~(int64_t)tasks->size());
+                tasks->push_back(Task{slot, heap, depth, bd, bf, std::move(faces), Arena()});
+                return;
+            }
+            const int a = (depth + 2) % 3;   // depth%3: 1 -> x, 2 -> y, 0 -> z (js/8-kd_tree.js:1689-1702)
+            BoxD cb[2] = {bd, bd};
+            BoxF cf[2] = {bf, bf};
+            const double ext = bd.hi[a] - bd.lo[a];
+            for (int i = 0; i < 2; i++) {
+                cb[i].lo[a] = bd.lo[a] + 0.5 * i * ext;
+                cb[i].hi[a] = bd.lo[a] + 0.5 * (i + 1) * ext;
+            }
+            const float split = bf.lo[a] + 0.5f * (bf.hi[a] - bf.lo[a]);
+            cf[0].hi[a] = split;
+            cf[1].lo[a] = split;
+            std::vector<uint32_t> cfaces[2];
+            for (int i = 0; i < 2; i++) {
+                cfaces[i].reserve(faces.size());
+                for (uint32_t f : faces)
+                    if (tri_box_overlap(mesh, cb[i], f)) cfaces[i].push_back(f);
+            }
+            std::vector<uint32_t>().swap(faces);
+            const uint32_t base = (uint32_t)A.nodes.size();
+            A.nodes.resize(base + 2);
+            A.heap.resize(base + 2);
+            A.nodes[slot].split = split;
+            A.nodes[slot].info = T_INTERNAL | ((uint32_t)a << 28) | base;
+            A.n_internal++;
+            // the reference pushes child 0 then child 1 and pops child 1 first (js/8-kd_tree.js:1677,:1718):
+            // leaves are numbered upper subtree first
+            node(A, base + 1, 2 * heap + 2, depth + 1, cb[1], cf[1], std::move(cfaces[1]), top);
+            node(A, base + 0, 2 * heap + 1, depth + 1, cb[0], cf[0], std::move(cfaces[0]), top);
+            return;
+        }
+        A.nodes[slot].split = 0.0f;
+        if (faces.empty()) {
+            A.nodes[slot].info = T_EMPTY;
+            A.n_empty++;
+            return;
+        }
+        KdLeafDev lf = {{-1, -1, -1, -1}};
+        for (size_t i = 0; i < std::min<size_t>(faces.size(), 4); i++) lf.face[i] = (int32_t)faces[i];
+        if (top) events->push_back((int64_t)A.leaves.size());
+        A.nodes[slot].info = T_LEAF | (uint32_t)A.leaves.size();
+        A.leaves.push_back(lf);
+        A.n_leaf++;
+    }
+};
+
+}  // namespace
+
+void build_kdtree(const double *verts, int64_t n_verts, const uint32_t *faces, int64_t n_faces, int max_depth,
+                  double infinity, int n_threads, KdTreeHost &out) {
+    (void)n_verts;
+    if (max_depth > 24) max_depth = 24;
+    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+
+    // root box: x from vertex 0, y from vertex 1, z from vertex 2 of each face (js/8-kd_tree.js:1657-1669)
+    BoxD rb;
+    for (int k = 0; k < 3; k++) { rb.lo[k] = infinity; rb.hi[k] = -infinity; }
+    for (int64_t i = 0; i < n_faces; i++) {
+        for (int k = 0; k < 3; k++) {
+            double c = verts[3 * (size_t)faces[3 * i + k] + k];
+            rb.lo[k] = std::fmin(rb.lo[k], c);
+            rb.hi[k] = std::fmax(rb.hi[k], c);
+        }
+    }
+    BoxF rf;
+    for (int k = 0; k < 3; k++) { rf.lo[k] = (float)rb.lo[k]; rf.hi[k] = (float)rb.hi[k]; }
+
+    std::vector<Task> tasks;
+    std::vector<int64_t> events;
+    Builder B{{verts, faces}, max_depth, (n_threads > 1 && n_faces > 2048) ? 8 : 0, &tasks, &events};
+    Arena top;
+    top.nodes.resize(1);
+    top.heap.resize(1);
+    std::vector<uint32_t> all((size_t)n_faces);
+    for (int64_t i = 0; i < n_faces; i++) all[(size_t)i] = (uint32_t)i;
+    B.node(top, 0, 0, 1, rb, rf, std::move(all), true);
+
+    // subtrees in parallel, largest first
+    if (!tasks.empty()) {
+        std::vector<size_t> order(tasks.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        std::sort(order.begin(), order.end(),
+                  [&](size_t a, size_t b) { return tasks[a].faces.size() > tasks[b].faces.size(); });
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            Builder W{{verts, faces}, max_depth, 0, nullptr, nullptr};
+            for (;;) {
+                size_t k = next.fetch_add(1);
+                if (k >= order.size()) break;
+                Task &t = tasks[order[k]];
+                t.arena.nodes.resize(1);
+                t.arena.heap.resize(1);
+                W.node(t.arena, 0, t.heap, t.depth, t.bd, t.bf, std::move(t.faces), false);
+            }
+        };
+        std::vector<std::thread> pool;
+        int nt = (int)std::min<size_t>((size_t)n_threads, tasks.size());
+        for (int i = 1; i < nt; i++) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+    }
+
+    // stitch: leaf numbers follow the DFS event order; task nodes are appended behind the top arena
+    std::vector<uint32_t> top_leaf_global(top.leaves.size());
+    std::vector<uint32_t> task_leaf_base(tasks.size()), task_node_base(tasks.size());
+    uint64_t n_leaves = 0, n_nodes = top.nodes.size();
+    for (int64_t ev : events) {
+        if (ev >= 0) top_leaf_global[(size_t)ev] = (uint32_t)n_leaves++;
+        else { size_t k = (size_t)~ev; task_leaf_base[k] = (uint32_t)n_leaves; n_leaves += tasks[k].arena.leaves.size(); }
+    }
+    for (size_t k = 0; k < tasks.size(); k++) { task_node_base[k] = (uint32_t)n_nodes; n_nodes += tasks[k].arena.nodes.size() - 1; }
+
+    out.nodes.assign((size_t)n_nodes, KdNodeDev{0.0f, 0u});
+    out.heap_index.assign((size_t)n_nodes, 0u);
+    out.leaves.assign((size_t)n_leaves, KdLeafDev{{-1, -1, -1, -1}});
+    out.depth = top.depth;
+    out.n_internal = top.n_internal; out.n_leaf = top.n_leaf; out.n_empty = top.n_empty;
+    for (size_t s = 0; s < top.nodes.size(); s++) {
+        KdNodeDev n = top.nodes[s];
+        if ((n.info >> 30) == 3) {
+            uint32_t li = n.info & 0x3fffffffu;
+            n.info = T_LEAF | top_leaf_global[li];
+            out.leaves[top_leaf_global[li]] = top.leaves[li];
+        }
+        out.nodes[s] = n;
+        out.heap_index[s] = top.heap[s];
+    }
+    for (size_t k = 0; k < tasks.size(); k++) {
+        const Arena &A = tasks[k].arena;
+        const uint32_t nb = task_node_base[k], lb = task_leaf_base[k];
+        auto fix = [&](KdNodeDev n) {
+            uint32_t ty = n.info >> 30;
+            if (ty == 1) n.info = (n.info & 0xf0000000u) | (nb + (n.info & 0x0fffffffu) - 1);
+            else if (ty == 3) n.info = T_LEAF | (lb + (n.info & 0x3fffffffu));
+            return n;
+        };
+        out.nodes[tasks[k].top_slot] = fix(A.nodes[0]);
+        out.heap_index[tasks[k].top_slot] = A.heap[0];
+        for (size_t j = 1; j < A.nodes.size(); j++) {
+            out.nodes[nb + j - 1] = fix(A.nodes[j]);
+            out.heap_index[nb + j - 1] = A.heap[j];
+        }
+        for (size_t j = 0; j < A.leaves.size(); j++) out.leaves[lb + j] = A.leaves[j];
+        out.depth = std::max(out.depth, A.depth);
+        out.n_internal += A.n_internal; out.n_leaf += A.n_leaf; out.n_empty += A.n_empty;
+    }
+    for (int k = 0; k < 3; k++) { out.root_box[k] = rb.lo[k]; out.root_box[3 + k] = rb.hi[k]; }
+}
+
+void export_reference(const KdTreeHost &t, uint32_t *pairs) {
+    std::vector<std::pair<uint32_t, uint32_t>> v(t.nodes.size());
+    for (size_t i = 0; i < t.nodes.size(); i++) {
+        uint32_t info = t.nodes[i].info, ty = info >> 30;
+        uint32_t meta = ty == 1 ? T_INTERNAL : (ty == 2 ? T_EMPTY : (T_LEAF | (info & 0x3fffffffu)));
+        v[i] = {t.heap_index[i], meta};
+    }
+    std::sort(v.begin(), v.end());
+    for (size_t i = 0; i < v.size(); i++) { pairs[2 * i] = v[i].first; pairs[2 * i + 1] = v[i].second; }
+}
+
+}  // namespace rt

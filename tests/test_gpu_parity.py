@@ -1,0 +1,171 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same scenes.
+
+Bar: primary hit ids identical, pre-tone RGBA8 identical, float colour identical (the kernels and the
+oracle follow one arithmetic contract: no FMA, IEEE divide/sqrt, the same deterministic pow), ray
+counts identical; Lbar/sf to 1e-12 relative (the double-precision sum is order-dependent at that level)."""
+import numpy as np
+import pytest
+
+from helpers import make_flat, manifest, sha
+from oracle import oracle
+from ray_tracer_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def render_hip(flat):
+    rt = abi.RayTracerHIP(flat.cfg)
+    rt.setScene(flat)
+    rt.trace()
+    return rt
+
+
+def check_against_oracle(flat, rect=None, threads=16):
+    rt = render_hip(flat)
+    got_f, got_8, got_id = rt.readFloat(), rt.readRGBA8(), rt.readHitIds()
+    o = oracle.OracleRenderer(flat)
+    want_f, want_8, want_id, cn = o.trace(rect=rect, threads=threads)
+    if rect:
+        x0, y0, x1, y1 = rect
+        sl = (slice(y0, y1), slice(x0, x1))
+    else:
+        sl = (slice(None), slice(None))
+    ids_ok = got_id[sl] == want_id[sl]
+    assert ids_ok.all(), "hit ids differ at %d pixels" % (~ids_ok).sum()
+    d8 = np.abs(got_8[sl].astype(int) - want_8[sl].astype(int))
+    assert d8.max() == 0, "RGBA8 differs at %d pixels, max %d" % ((d8.max(axis=-1) > 0).sum(), d8.max())
+    same_f = (got_f[sl] == want_f[sl]) | (np.isnan(got_f[sl]) & np.isnan(want_f[sl]))
+    assert same_f.all(), "float colour differs at %d values" % (~same_f).sum()
+    st = rt.stats()
+    if not rect:
+        assert st.rays_total == cn.rays and st.shadow_rays == cn.shadow_rays
+        assert list(st.rays_per_level)[:5] == list(cn.rays_level)[:5]
+    return rt, o, (got_f, got_8, got_id), cn
+
+
+def test_config1_checkpoint6_scene_depth5():
+    """BASELINE config 1: checkpoint-6 scene (analytic primitives, one set light of two, INFINITY 100000.1)."""
+    flat = make_flat(None, 640, 480, depth=5, time=None, second_light=False, infinity=100000.1)
+    check_against_oracle(flat)
+
+
+def test_default_scene_res4_depth1():
+    flat = make_flat("bun_zipper_res4.ply", 640, 480, depth=1)
+    check_against_oracle(flat)
+
+
+def test_default_scene_res4_depth5_reflective_mesh():
+    flat = make_flat("bun_zipper_res4.ply", 640, 480, depth=5, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    check_against_oracle(flat)
+
+
+def test_config2_res4_1920x1080():
+    """BASELINE config 2: res4 bunny, primary rays + Phong, 1920x1080, light at t = 7.5 s."""
+    flat = make_flat("bun_zipper_res4.ply", 1920, 1080, depth=1, time=7.5)
+    check_against_oracle(flat)
+
+
+def test_brute_force_triangles_match():
+    flat = make_flat("bun_zipper_res4.ply", 160, 120, depth=2, use_kd_tree=0)
+    check_against_oracle(flat)
+
+
+def test_ragged_frame_and_supersampling():
+    # width/height not multiples of the 8x8 tile; 2x2 supersampling -> 202 x 150 target
+    flat = make_flat("bun_zipper_res4.ply", 101, 75, depth=3, ss=2)
+    rt, o, (gf, g8, gid), cn = check_against_oracle(flat)
+    Lbar, sf = rt.tone()
+    wl, ws = o.tone(g8)
+    assert abs(Lbar - wl) <= 1e-12 * wl and abs(sf - ws) <= 1e-12 * ws
+    assert np.array_equal(rt.present(), o.present(g8, wl, ws))
+    flat.cfg.tr_method = 1
+    rt2 = render_hip(flat)
+    rt2.tone()
+    assert np.array_equal(rt2.present(), oracle.OracleRenderer(flat).present(g8, wl, ws))
+
+
+def test_kdtree_export_through_gpu_context():
+    m = manifest("k8_res3_640x480")
+    flat = make_flat("bun_zipper_res3.ply", 64, 48)
+    rt = abi.RayTracerHIP(flat.cfg)
+    rt.setScene(flat)
+    pairs, leaves, box = rt.exportKdTree()
+    assert sha(pairs) == m["kd"]["sha256"]["nodes_sparse_u32"] and sha(leaves) == m["kd"]["sha256"]["leaves_i32"]
+    assert sha(box) == m["kd"]["sha256"]["root_box_f64"]
+
+
+def test_empty_mesh_and_no_primitives():
+    flat = make_flat(None, 64, 48, depth=2)
+    flat.prims = []
+    rt = render_hip(flat)
+    assert (rt.readHitIds() == -1).all()
+    assert (rt.readRGBA8()[..., :3] == np.array([26, 128, 230], np.uint8)).all()
+    assert rt.stats().rays_total == 64 * 48 and rt.stats().shadow_rays == 0
+
+
+def test_sharded_render_assembles_to_the_full_frame():
+    """Two shard contexts on one GPU: tiles interleave, partial tone sums add up, the assembled frame
+    equals the unsharded one byte for byte."""
+    import ctypes as C
+    flat = make_flat("bun_zipper_res4.ply", 203, 117, depth=3)
+    full = render_hip(flat)
+    want = full.readRGBA8()
+    ws, wn = full.tonePartial()
+    parts, sums, cnt = [], 0.0, 0
+    L = abi.lib()
+    hip = C.CDLL("libamdhip64.so")
+    bufs = []
+    for r in range(2):
+        flat.cfg.shard_index, flat.cfg.shard_count = r, 2
+        rt = render_hip(flat)
+        s, n = rt.tonePartial()
+        sums += s
+        cnt += n
+        p, nb = C.c_void_p(), C.c_size_t()
+        assert L.rt_device_shard_rgba8(rt.ctx, C.byref(p), C.byref(nb)) == 0
+        host = np.zeros(nb.value, np.uint8)
+        assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), p, C.c_size_t(nb.value), 2) == 0
+        bufs.append(host)
+        parts.append(rt)
+    flat.cfg.shard_index, flat.cfg.shard_count = 0, 1
+    assert cnt == wn == 203 * 117
+    assert abs(sums - ws) <= 1e-12 * abs(ws)
+    stride = max(len(b) for b in bufs)
+    gathered = np.zeros(stride * 2, np.uint8)
+    for r, b in enumerate(bufs):
+        gathered[r * stride:r * stride + len(b)] = b
+    root = abi.RayTracerHIP(flat.cfg)
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), C.c_size_t(len(gathered))) == 0
+    assert hip.hipMemcpy(dptr, C.c_void_p(gathered.ctypes.data), C.c_size_t(len(gathered)), 1) == 0
+    assert L.rt_assemble_shards(root.ctx, dptr, C.c_size_t(stride), 2) == 0
+    assert np.array_equal(root.readRGBA8(), want)
+    hip.hipFree(dptr)
+
+
+def test_full_size_config3_properties_and_sampled_parity():
+    """BASELINE config 3 at full size (69k-triangle bunny, depth 5, 3840x2160): parity with the oracle on
+    three 96x64 windows (sky+floor, sphere, bunny) and frame-level properties: idempotence (two traces give
+    the same bytes), ray accounting, background pixels exact."""
+    flat = make_flat("bun_zipper.ply", 3840, 2160, depth=5, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    rt = render_hip(flat)
+    a8, af, aid = rt.readRGBA8(), rt.readFloat(), rt.readHitIds()
+    st = rt.stats()
+    assert st.pixels == 3840 * 2160 and st.rays_per_level[0] == st.pixels
+    assert st.rays_total == sum(st.rays_per_level)
+    for l in range(1, 5):
+        assert st.rays_per_level[l] <= 2 * st.rays_per_level[l - 1]
+    miss = aid == -1
+    assert miss.any() and (a8[miss][:, :3] == np.array([26, 128, 230], np.uint8)).all()
+    rt.trace()
+    assert np.array_equal(rt.readRGBA8(), a8)
+    o = oracle.OracleRenderer(flat)
+    for rect in ((3700, 2050, 3796, 2114), (1900, 1000, 1996, 1064), (2000, 1900, 2096, 1964), (600, 300, 696, 364)):
+        wf, w8, wid, _ = o.trace(rect=rect, threads=16)
+        sl = (slice(rect[1], rect[3]), slice(rect[0], rect[2]))
+        assert np.array_equal(aid[sl], wid[sl]), rect
+        assert np.array_equal(a8[sl], w8[sl]), rect
+        assert ((af[sl] == wf[sl]) | (np.isnan(af[sl]) & np.isnan(wf[sl]))).all(), rect
+    Lbar, sf = rt.tone()
+    wl, ws = o.tone(a8)
+    assert abs(Lbar - wl) <= 1e-12 * wl and abs(sf - ws) <= 1e-12 * ws

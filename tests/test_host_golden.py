@@ -1,0 +1,218 @@
+"""CPU tests: everything on the host half of the path is pinned bit-exactly against fixtures produced by
+running the reference's own JavaScript under Node (oracle/gen_golden/ref_capture.js):
+uniforms (matrices, camera rays, light animation), mesh ingest (f64 vertices, faces, face materials),
+the k-d tree arrays of the ORACLE builder and of the PRODUCT builder (host-only context), Lbar / sf."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, ROOT, lcg_bytes_fast, make_flat, manifest, model, sha, uniforms
+from oracle import oracle
+from ray_tracer_amd import abi, scene
+
+MESHES = [("bun_zipper_res4.ply", "k8_res4_640x480"), ("bun_zipper_res3.ply", "k8_res3_640x480"),
+          ("bun_zipper_res2.ply", "k8_res2_640x480"), ("bun_zipper.ply", "k8_full_640x480")]
+
+
+def f32(x):
+    return np.asarray(x, dtype=np.float64).astype(np.float32)
+
+
+@pytest.mark.parametrize("gold,w,h,t", [("k8_res4_640x480", 640, 480, 0.0), ("c2_res4_1920x1080", 1920, 1080, 7.5),
+                                        ("c3_rays_3840x2160", 3840, 2160, 0.0)])
+def test_uniforms_match_reference(gold, w, h, t):
+    m = manifest(gold)
+    U = uniforms(m)
+    flat = make_flat("bun_zipper_res4.ply", w, h, time=t)
+    assert m["glsl_counts"]["intersect_order"] == ["Sphere", "Sphere", "Rect", "Cube", "Cylinder"]
+    kinds = {"Plane": 0, "Rect": 1, "Sphere": 2, "Cube": 3, "Cylinder": 4}
+    for i, (kind, mt, mi, M, IM) in enumerate(flat.prims):
+        assert kind == kinds[m["glsl_counts"]["intersect_order"][i]]
+        assert [mt, mi] == m["glsl_counts"]["material_consts"][i]
+        assert np.array_equal(f32(M), f32(U["model%d" % i])), i
+        assert np.array_equal(f32(IM), f32(U["invModel%d" % i])), i
+    for n in ("ray00", "ray01", "ray10", "ray11"):
+        assert np.array_equal(getattr(flat, n), f32(U[n])), n
+    assert np.array_equal(flat.cam, f32(U["cameraPos"]))
+    assert flat.n_lights_loop == m["glsl_counts"]["light_loop"] == 2
+    for i, (p, c) in enumerate(flat.lights):
+        assert np.array_equal(f32(p), f32(U["pointLights[%d].position" % i]))
+        assert np.array_equal(f32(c), f32(U["pointLights[%d].color" % i]))
+    names = {0: "phongMaterials", 1: "phongBlinnMaterials", 2: "phongCheckeredMaterials"}
+    for (t_, id_, ka, kd, ks, ke, kr, kt, ior, Co, Co2, Cs) in flat.mats:
+        base = "%s[%d]." % (names[t_], id_)
+        for key, val in (("ka", ka), ("kd", kd), ("ks", ks), ("ke", ke), ("kReflect", kr), ("kRefract", kt), ("ior", ior)):
+            assert f32(val) == f32(U[base + key][0]), base + key
+        assert np.array_equal(f32(Cs), f32(U[base + "Cs"]))
+        assert np.array_equal(f32(Co), f32(U[base + ("Co1" if t_ == 2 else "Co")]))
+        if t_ == 2:
+            assert np.array_equal(f32(Co2), f32(U[base + "Co2"]))
+    assert np.array_equal(flat.ambient, f32(U["ambientLight"])) and np.array_equal(flat.bg, f32(U["bgColor"]))
+    # kdBoxMin/Max uniforms = f32 of the builder's root box
+    _, _, box, _ = oracle.kd_build(flat.verts, flat.faces)
+    assert np.array_equal(f32(box[:3]), f32(U["kdBoxMin"])) and np.array_equal(f32(box[3:]), f32(U["kdBoxMax"]))
+
+
+def test_checkpoint6_uniforms():
+    m = manifest("c1_ch6_640x480")
+    U = uniforms(m)
+    flat = make_flat(None, 640, 480, depth=5, time=None, second_light=False, infinity=100000.1)
+    assert m["glsl_counts"]["light_loop"] == 2 and flat.n_lights_loop == 2 and len(flat.lights) == 1
+    assert "pointLights[1].position" not in U
+    assert m["n_triangles_ch6"] == 0 and flat.cfg.render_triangles == 0
+    assert m["glsl_counts"]["ray_tree_size"] == 31
+    for i, (kind, mt, mi, M, IM) in enumerate(flat.prims):
+        assert np.array_equal(f32(M), f32(U["model%d" % i])) and np.array_equal(f32(IM), f32(U["invModel%d" % i]))
+    assert np.array_equal(f32(flat.lights[0][0]), f32(U["pointLights[0].position"]))
+
+
+@pytest.mark.parametrize("ply,gold", MESHES)
+def test_mesh_ingest_matches_reference(ply, gold):
+    m = manifest(gold)
+    sc = scene.default_scene(model(ply))
+    v, f, fm = sc.mesh_arrays()
+    assert (len(v), len(f)) == (m["n_verts"], m["n_faces"])
+    assert sha(v) == m["sha256"]["verts_f64"]
+    assert sha(v.astype(np.float32)) == m["sha256"]["verts_f32"]
+    assert sha(f) == m["sha256"]["faces_u32"] and sha(fm) == m["sha256"]["face_mat_u32"]
+    assert list(v[0]) == m["first_vert_f64"]
+
+
+@pytest.mark.parametrize("ply,gold", MESHES)
+def test_oracle_kd_builder_bit_exact(ply, gold):
+    m = manifest(gold)
+    sc = scene.default_scene(model(ply))
+    v, f, _ = sc.mesh_arrays()
+    pairs, leaves, box, depth = oracle.kd_build(v, f)
+    kd = m["kd"]
+    assert (len(pairs), len(leaves), depth) == (kd["n_nodes"], kd["n_leaves"], kd["depth"])
+    assert sha(pairs) == kd["sha256"]["nodes_sparse_u32"]
+    assert sha(leaves) == kd["sha256"]["leaves_i32"]
+    assert sha(box) == kd["sha256"]["root_box_f64"] and list(box) == kd["root_box_f64"]
+    full = os.path.join(GOLDEN, gold, "kd_nodes_sparse_u32.bin")
+    if os.path.exists(full):
+        assert np.array_equal(pairs.ravel(), np.fromfile(full, np.uint32))
+        assert np.array_equal(leaves.ravel(), np.fromfile(os.path.join(GOLDEN, gold, "kd_leaves_i32.bin"), np.int32))
+
+
+@pytest.mark.parametrize("ply,gold", MESHES)
+def test_product_kd_builder_bit_exact(ply, gold):
+    """The threaded product builder behind rt_build_kdtree, through the C ABI on a host-only context."""
+    m = manifest(gold)
+    sc = scene.default_scene(model(ply))
+    v, f, fm = sc.mesh_arrays()
+    rt = abi.RayTracerHIP(abi.default_config(device=-1))
+    rt.setMesh(v, f, fm)
+    rt.buildKdTree()
+    pairs, leaves, box = rt.exportKdTree()
+    kd = m["kd"]
+    assert sha(pairs) == kd["sha256"]["nodes_sparse_u32"]
+    assert sha(leaves) == kd["sha256"]["leaves_i32"]
+    assert sha(box) == kd["sha256"]["root_box_f64"]
+    types = pairs[:, 1] >> 30
+    assert (int((types == 1).sum()), int((types == 3).sum()), int((types == 2).sum())) == (kd["n_internal"], kd["n_leaf"], kd["n_empty"])
+    rt.close()
+
+
+def test_kd_edge_cases():
+    rt = abi.RayTracerHIP(abi.default_config(device=-1))
+    # empty mesh: a single EMPTY_LEAF root, no leaves
+    rt.setMesh(np.zeros((0, 3)), np.zeros((0, 3), np.uint32), np.zeros((0, 2), np.uint32))
+    rt.buildKdTree()
+    pairs, leaves, box = rt.exportKdTree()
+    assert pairs.tolist() == [[0, 2 << 30]] and len(leaves) == 0
+    assert box.tolist() == [100000.0] * 3 + [-100000.0] * 3
+    # three faces: one leaf holding all of them, padded with -1
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float64)
+    f = np.array([[0, 1, 2], [0, 1, 3], [1, 2, 3]], np.uint32)
+    rt.setMesh(v, f, np.zeros((3, 2), np.uint32))
+    rt.buildKdTree()
+    pairs, leaves, _ = rt.exportKdTree()
+    assert pairs.tolist() == [[0, (3 << 30) | 0]] and leaves.tolist() == [[0, 1, 2, -1]]
+    op, ol, _, _ = oracle.kd_build(v, f)
+    assert np.array_equal(op, pairs) and np.array_equal(ol, leaves)
+    # bad face index is rejected
+    with pytest.raises(abi.RTError):
+        rt.setMesh(v, np.array([[0, 1, 9]], np.uint32), np.zeros((1, 2), np.uint32))
+    rt.close()
+
+
+def test_kd_random_meshes_match_oracle():
+    rng = np.random.default_rng(7)
+    for n_faces in (5, 40, 700, 3000):
+        v = rng.uniform(-50, 50, size=(n_faces * 2, 3))
+        f = rng.integers(0, len(v), size=(n_faces, 3)).astype(np.uint32)
+        # keep triangles small so the tree gets deep
+        v[f[:, 1]] = v[f[:, 0]] + rng.normal(0, 2.0, size=(n_faces, 3))
+        v[f[:, 2]] = v[f[:, 0]] + rng.normal(0, 2.0, size=(n_faces, 3))
+        rt = abi.RayTracerHIP(abi.default_config(device=-1))
+        rt.setMesh(v, f, np.zeros((n_faces, 2), np.uint32))
+        rt.buildKdTree()
+        pairs, leaves, box = rt.exportKdTree()
+        op, ol, ob, _ = oracle.kd_build(v, f)
+        assert np.array_equal(op, pairs) and np.array_equal(ol, leaves) and np.array_equal(ob, box)
+        rt.close()
+
+
+@pytest.mark.parametrize("gold,ss,pattern", [("k8_res4_640x480", 1, "lcg"), ("project_640x480", 2, "lcg"),
+                                             ("tone7_zero_640x480", 2, "zero"), ("tone7_const_640x480", 2, "const")])
+def test_oracle_tone_matches_reference(gold, ss, pattern):
+    m = manifest(gold)
+    n = 640 * ss * 480 * ss
+    if pattern == "lcg":
+        px = lcg_bytes_fast(n * 4)
+    elif pattern == "zero":
+        px = np.zeros(n * 4, np.uint8)
+    else:
+        px = np.tile(np.array([10, 200, 30, 255], np.uint8), n)
+    flat = make_flat(None, 640, 480, ss=ss)
+    o = oracle.OracleRenderer(flat)
+    Lbar, sf = o.tone(px)
+    assert abs(Lbar - m["Lbar"]) <= 1e-12 * m["Lbar"], (Lbar, m["Lbar"])
+    assert abs(sf - m["sf"]) <= 1e-12 * m["sf"], (sf, m["sf"])
+
+
+def test_lcg_helper():
+    from helpers import lcg_bytes
+    assert np.array_equal(lcg_bytes(5000), lcg_bytes_fast(5000))
+
+
+def test_abi_exports_every_declared_symbol():
+    """Every function declared in include/rt_hip.h is exported by the built library (no compute calls)."""
+    with open(os.path.join(ROOT, "include", "rt_hip.h")) as f:
+        text = f.read()
+    names = sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) >= 25
+    lib = C.CDLL(abi.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_struct_layouts_match_c():
+    """ctypes mirrors of the ABI structs have the sizes the C compiler gives them."""
+    src = '#include "include/rt_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n",sizeof(rt_config),sizeof(rt_prim),sizeof(rt_material),sizeof(rt_light),sizeof(rt_stats));return 0;}'
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "s.c")
+        open(p, "w").write(src)
+        subprocess.check_call(["gcc", "-I", ROOT, "-o", os.path.join(d, "s"), p])
+        out = subprocess.check_output([os.path.join(d, "s")]).split()
+    got = [C.sizeof(x) for x in (abi.Config, abi.Prim, abi.Material, abi.Light, abi.Stats)]
+    assert got == [int(x) for x in out]
+
+
+def test_host_only_context_refuses_gpu_calls():
+    rt = abi.RayTracerHIP(abi.default_config(device=-1))
+    with pytest.raises(abi.RTError, match="host-only"):
+        rt.trace()
+    rt.close()
+
+
+def test_create_rejects_bad_config():
+    for kw in ({"width": 0}, {"max_depth": 0}, {"max_depth": 9}, {"supersampling": 0}, {"shard_index": 3, "shard_count": 2}):
+        with pytest.raises(abi.RTError):
+            abi.RayTracerHIP(abi.default_config(device=-1, **kw))
