@@ -2,7 +2,9 @@
 
 Bar: primary hit ids identical, pre-tone RGBA8 identical, float colour identical (the kernels and the
 oracle follow one arithmetic contract: no FMA, IEEE divide/sqrt, the same deterministic pow), ray
-counts identical; Lbar/sf to 1e-12 relative (the double-precision sum is order-dependent at that level)."""
+counts identical; Lbar/sf to 1e-10 relative: the reference adds log(L)/N term by term in pixel order in
+double precision, which carries ~N*2^-53 of rounding noise (3e-12 at 30k pixels, 1e-9 at 4K); the GPU
+reduction sums in a different order."""
 import numpy as np
 import pytest
 
@@ -11,6 +13,7 @@ from oracle import oracle
 from ray_tracer_amd import abi
 
 pytestmark = pytest.mark.gpu
+TONE_RTOL = 1e-10
 
 
 def render_hip(flat):
@@ -76,7 +79,7 @@ def test_ragged_frame_and_supersampling():
     rt, o, (gf, g8, gid), cn = check_against_oracle(flat)
     Lbar, sf = rt.tone()
     wl, ws = o.tone(g8)
-    assert abs(Lbar - wl) <= 1e-12 * wl and abs(sf - ws) <= 1e-12 * ws
+    assert abs(Lbar - wl) <= TONE_RTOL * wl and abs(sf - ws) <= TONE_RTOL * ws
     assert np.array_equal(rt.present(), o.present(g8, wl, ws))
     flat.cfg.tr_method = 1
     rt2 = render_hip(flat)
@@ -168,4 +171,5 @@ def test_full_size_config3_properties_and_sampled_parity():
         assert ((af[sl] == wf[sl]) | (np.isnan(af[sl]) & np.isnan(wf[sl]))).all(), rect
     Lbar, sf = rt.tone()
     wl, ws = o.tone(a8)
-    assert abs(Lbar - wl) <= 1e-12 * wl and abs(sf - ws) <= 1e-12 * ws
+    assert abs(Lbar - wl) <= 1e-8 * wl and abs(sf - ws) <= 1e-8 * ws      # 8.3 M sequential adds in the reference
+    assert np.float32(sf) == np.float32(ws)                                 # what the present shader receives
