@@ -166,13 +166,16 @@ int rt_tone_partial(rt_ctx *ctx, double *sum_log, uint64_t *count);
 int rt_tone_finish(rt_ctx *ctx, double sum_log, uint64_t count, double *Lbar, double *sf);
 /* single-GPU convenience: rt_tone_partial + rt_tone_finish */
 int rt_tone(rt_ctx *ctx, double *Lbar, double *sf);
-/* present pass (js/8-kd_tree.js:85-143): SxS box filter, tone operator, canvas RGBA8 */
+/* present pass (js/8-kd_tree.js:85-143): SxS box filter, tone operator, canvas RGBA8.
+ * canvas_rgba may be NULL: the canvas then stays in device memory (rt_device_canvas) */
 int rt_present(rt_ctx *ctx, uint8_t *canvas_rgba);
 
 /* ---- device-resident access for multi-GPU gathers (no host round trip) ------------------- */
 /* device pointer of the RGBA8 render target (width*S*height*S*4 bytes) */
 int rt_device_rgba8(rt_ctx *ctx, void **dptr, size_t *bytes);
 int rt_device_float(rt_ctx *ctx, void **dptr, size_t *bytes);
+/* device pointer of the presented canvas (width*height*4 bytes) */
+int rt_device_canvas(rt_ctx *ctx, void **dptr, size_t *bytes);
 /* this context's shard of the RGBA8 target in compact tile order: [tile of the shard][64 pixels of the
  * 8x8 tile, row-major][4 bytes]; alpha 0 marks lanes of edge tiles that fall outside the image.
  * bytes = 256 * (number of tiles of the shard). */

@@ -57,11 +57,24 @@ def kd_build(verts_f64, faces_u32, max_depth=24, infinity=100000.0):
 
 
 class Counters(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("rays_level", C.c_uint64 * 8), ("rays_in_box", C.c_uint64),
-                ("kd_steps", C.c_uint64), ("kd_leaf_visits", C.c_uint64), ("kd_tri_tests", C.c_uint64),
-                ("shadow_rays", C.c_uint64), ("shadow_in_box", C.c_uint64),
-                ("sh_steps", C.c_uint64), ("sh_leaf_visits", C.c_uint64), ("sh_tri_tests", C.c_uint64),
-                ("prim_tests", C.c_uint64)]
+    A8 = C.c_uint64 * 8
+    _fields_ = [("rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("rays_level", A8), ("rays_in_box", A8),
+                ("kd_steps", A8), ("kd_leaf_visits", A8), ("kd_tri_tests", A8),
+                ("shadow_level", A8), ("shadow_in_box", A8),
+                ("sh_steps", A8), ("sh_leaf_visits", A8), ("sh_tri_tests", A8),
+                ("prim_tests", A8), ("sh_prim_tests", A8)]
+
+    def algorithmic(self, level=None):
+        """Bytes and flops the REFERENCE algorithm moves/does for the counted rays: per ray
+        bytes = 8*steps + 16*leafVisits + 48*triTests + 128*primTests, flops = 14*steps + 45*triTests + 60*primTests
+        (closest-hit and shadow rays alike). level=None sums all levels."""
+        lv = range(8) if level is None else [level]
+        st = sum(self.kd_steps[l] + self.sh_steps[l] for l in lv)
+        lf = sum(self.kd_leaf_visits[l] + self.sh_leaf_visits[l] for l in lv)
+        tr = sum(self.kd_tri_tests[l] + self.sh_tri_tests[l] for l in lv)
+        pr = sum(self.prim_tests[l] + self.sh_prim_tests[l] for l in lv)
+        return {"bytes": 8 * st + 16 * lf + 48 * tr + 128 * pr, "flops": 14 * st + 45 * tr + 60 * pr,
+                "steps": st, "leaf_visits": lf, "tri_tests": tr, "prim_tests": pr}
 
     def as_dict(self):
         d = {}

@@ -64,14 +64,17 @@ typedef struct oracle_scene {
     float kd_box_min[3], kd_box_max[3];
 } oracle_scene;
 
+/* Work counters of the REFERENCE algorithm (restart traversal), split by ray-tree level [0..7]. */
 typedef struct oracle_counters {
-    uint64_t rays;                  /* valid ray-tree nodes */
+    uint64_t rays;                  /* valid ray-tree nodes, all levels */
+    uint64_t shadow_rays;           /* all levels */
     uint64_t rays_level[8];
-    uint64_t rays_in_box;           /* closest-hit rays whose k-d loop ran at least once */
-    uint64_t kd_steps, kd_leaf_visits, kd_tri_tests;       /* closest-hit traversal */
-    uint64_t shadow_rays, shadow_in_box;
-    uint64_t sh_steps, sh_leaf_visits, sh_tri_tests;       /* any-hit traversal */
-    uint64_t prim_tests;            /* analytic primitive tests, both kinds of ray */
+    uint64_t rays_in_box[8];        /* closest-hit rays whose k-d loop ran at least once */
+    uint64_t kd_steps[8], kd_leaf_visits[8], kd_tri_tests[8];       /* closest-hit traversal */
+    uint64_t shadow_level[8], shadow_in_box[8];
+    uint64_t sh_steps[8], sh_leaf_visits[8], sh_tri_tests[8];       /* any-hit traversal */
+    uint64_t prim_tests[8];         /* analytic primitive tests of closest-hit rays */
+    uint64_t sh_prim_tests[8];      /* analytic primitive tests of shadow rays */
 } oracle_counters;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -319,7 +322,7 @@ static inline uint32_t kdNode(const oracle_scene *sc, int64_t idx) {
 typedef struct { float tMin; f3 normal, hitPoint, localHitPoint; int materialType, materialId, face; } Closest;
 
 static int kdTraverse(const oracle_scene *sc, f3 ro, f3 rd, HitInfo *h, int closest, Closest *best,
-                      oracle_counters *cn) {
+                      oracle_counters *cn, int lv) {
     float kdTMin, kdTMax;
     intersectRayAABB(sc, ro, rd, sc->kd_box_min, sc->kd_box_max, &kdTMin, &kdTMax);
     float maxDist = kdTMax;
@@ -341,7 +344,7 @@ static int kdTraverse(const oracle_scene *sc, f3 ro, f3 rd, HitInfo *h, int clos
             kdTMin = kdTMax;
             kdTMax = maxDist;
             while ((currNode >> 30) != RT_KD_EMPTY_LEAF && (currNode >> 30) != RT_KD_LEAF) {
-                if (closest) cn->kd_steps++; else cn->sh_steps++;
+                if (closest) cn->kd_steps[lv]++; else cn->sh_steps[lv]++;
                 int axis = currDepth % 3;
                 float split = comp(currBoxMin, axis) + 0.5f * (comp(currBoxMax, axis) - comp(currBoxMin, axis));
                 float t = (split - comp(ro, axis)) / comp(rd, axis);
@@ -377,13 +380,13 @@ static int kdTraverse(const oracle_scene *sc, f3 ro, f3 rd, HitInfo *h, int clos
                 }
             }
             if ((currNode >> 30) != RT_KD_EMPTY_LEAF) {
-                if (closest) cn->kd_leaf_visits++; else cn->sh_leaf_visits++;
+                if (closest) cn->kd_leaf_visits[lv]++; else cn->sh_leaf_visits[lv]++;
                 const int32_t *fi = sc->kd_leaves + 4 * (size_t)(currNode & 0x3fffffffu);
                 for (int i = 0; i < 4; i++) {
                     if (fi[i] > -1) {
                         f3 tv[3];
                         fetchTri(sc, fi[i], tv);
-                        if (closest) cn->kd_tri_tests++; else cn->sh_tri_tests++;
+                        if (closest) cn->kd_tri_tests[lv]++; else cn->sh_tri_tests[lv]++;
                         if (!closest) {
                             if (intersectTriangle(sc, ro, rd, h, tv)) return 1;
                         } else if (intersectTriangle(sc, ro, rd, h, tv) && h->t < best->tMin) {
@@ -401,25 +404,26 @@ static int kdTraverse(const oracle_scene *sc, f3 ro, f3 rd, HitInfo *h, int clos
             }
         }
     }
-    if (entered) { if (closest) cn->rays_in_box++; else cn->shadow_in_box++; }
+    if (entered) { if (closest) cn->rays_in_box[lv]++; else cn->shadow_in_box[lv]++; }
     return 0;
 }
 
-static int castShadow(const oracle_scene *sc, f3 ro, f3 rd, oracle_counters *cn) {
+static int castShadow(const oracle_scene *sc, f3 ro, f3 rd, oracle_counters *cn, int lv) {
     rd = normalize3(rd);
     HitInfo h; memset(&h, 0, sizeof h);
     cn->shadow_rays++;
+    cn->shadow_level[lv]++;
     for (int i = 0; i < sc->n_prims; i++) {
-        cn->prim_tests++;
+        cn->sh_prim_tests[lv]++;
         if (intersectPrim(sc, &sc->prims[i], ro, rd, &h)) return 1;
     }
     if (sc->cfg.render_triangles) {
         if (sc->cfg.use_kd_tree) {
-            if (kdTraverse(sc, ro, rd, &h, 0, NULL, cn)) return 1;
+            if (kdTraverse(sc, ro, rd, &h, 0, NULL, cn, lv)) return 1;
         } else {
             for (int32_t i = 0; i < sc->n_faces; i++) {
                 f3 tv[3]; fetchTri(sc, i, tv);
-                cn->sh_tri_tests++;
+                cn->sh_tri_tests[lv]++;
                 if (intersectTriangle(sc, ro, rd, &h, tv)) return 1;
             }
         }
@@ -433,7 +437,7 @@ static const rt_material *findMat(const oracle_scene *sc, int type, int id) {
 }
 
 static f3 illuminate(const oracle_scene *sc, const HitInfo *h, f3 rd, float *reflMix, float *refrMix,
-                     float *refrIdx, oracle_counters *cn) {
+                     float *refrIdx, oracle_counters *cn, int lv) {
     float ka = 0, kd = 0, ks = 0, ke = 0, kReflect = 0, kRefract = 0, ior = 0;
     f3 Co = F3(0, 0, 0), Cs = F3(0, 0, 0);
     const rt_material *m = findMat(sc, h->materialType, h->materialId);
@@ -463,7 +467,7 @@ static f3 illuminate(const oracle_scene *sc, const HitInfo *h, f3 rd, float *ref
         f3 Lp = F3(sc->lights[i].position[0], sc->lights[i].position[1], sc->lights[i].position[2]);
         f3 Lc = F3(sc->lights[i].color[0], sc->lights[i].color[1], sc->lights[i].color[2]);
         f3 S = normalize3(sub3(Lp, h->hitPoint));
-        int inShadow = castShadow(sc, add3(h->hitPoint, mul3(h->normal, sc->cfg.epsilon)), S, cn);
+        int inShadow = castShadow(sc, add3(h->hitPoint, mul3(h->normal, sc->cfg.epsilon)), S, cn, lv);
         if (!inShadow) {
             float SdotN = fmaxf(0.0f, dot3(S, N));
             float dc = clamp01(kd * SdotN);
@@ -509,13 +513,14 @@ static f3 shadePixel(const oracle_scene *sc, f3 primaryDir, int32_t *hit_id, ora
         if (!tree[node].valid) continue;
         f3 ro = tree[node].ro, rd = tree[node].rd;
         int level = 0; for (int n = node + 1; n > 1; n >>= 1) level++;
-        cn->rays++; cn->rays_level[level < 8 ? level : 7]++;
+        if (level > 7) level = 7;
+        cn->rays++; cn->rays_level[level]++;
         Closest best; memset(&best, 0, sizeof best);
         best.tMin = sc->cfg.infinity; best.face = -1;
         int prim_hit = -1;
         HitInfo h; memset(&h, 0, sizeof h);
         for (int i = 0; i < sc->n_prims; i++) {
-            cn->prim_tests++;
+            cn->prim_tests[level]++;
             if (intersectPrim(sc, &sc->prims[i], ro, rd, &h) && h.t < best.tMin) {
                 h.hit = 1;
                 best.hitPoint = add3(ro, mul3(rd, h.t));
@@ -530,11 +535,11 @@ static f3 shadePixel(const oracle_scene *sc, f3 primaryDir, int32_t *hit_id, ora
         }
         if (sc->cfg.render_triangles) {
             if (sc->cfg.use_kd_tree) {
-                kdTraverse(sc, ro, rd, &h, 1, &best, cn);
+                kdTraverse(sc, ro, rd, &h, 1, &best, cn, level);
             } else {
                 for (int32_t i = 0; i < sc->n_faces; i++) {
                     f3 tv[3]; fetchTri(sc, i, tv);
-                    cn->kd_tri_tests++;
+                    cn->kd_tri_tests[level]++;
                     if (intersectTriangle(sc, ro, rd, &h, tv) && h.t < best.tMin) {
                         h.hit = 1;
                         best.hitPoint = add3(ro, mul3(rd, h.t));
@@ -555,7 +560,7 @@ static f3 shadePixel(const oracle_scene *sc, f3 primaryDir, int32_t *hit_id, ora
             continue;
         }
         float kReflect = 0.0f, kRefract = 0.0f, ior = 0.0f;
-        tree[node].color = illuminate(sc, &h, rd, &kReflect, &kRefract, &ior, cn);
+        tree[node].color = illuminate(sc, &h, rd, &kReflect, &kRefract, &ior, cn, level);
 
         int outside = dot3(rd, h.normal) < 0.0f;
         f3 bias = mul3(h.normal, sc->cfg.epsilon);

@@ -9,4 +9,4 @@
 The directory name contains a hyphen, so it is imported through `rt_loader.load()` under the module
 name `ray_tracer_amd`.
 """
-from . import abi, scene, three_f32  # noqa: F401
+from . import abi, multi_gpu, scene, three_f32  # noqa: F401

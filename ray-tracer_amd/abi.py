@@ -139,6 +139,9 @@ def lib():
         L.rt_present.argtypes = [vp, vp]
         L.rt_device_rgba8.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.rt_device_float.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.rt_device_canvas.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.rt_device_shard_rgba8.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.rt_assemble_shards.argtypes = [vp, vp, C.c_size_t, i32]
         L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
         _lib = L
     return _lib

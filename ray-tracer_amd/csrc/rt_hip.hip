@@ -971,7 +971,6 @@ int rt_tone(rt_ctx *ctx, double *Lbar, double *sf) {
 int rt_present(rt_ctx *ctx, uint8_t *canvas) {
     if (!ctx) return -1;
     if (ctx->host_only) return fail(ctx, "rt_present: host-only context (created with device = -1)");
-    if (!canvas) return fail(ctx, "rt_present: null buffer");
     if (!ctx->traced) return fail(ctx, "rt_present: nothing traced yet");
     HIPCK(hipSetDevice(ctx->cfg.device));
     const rt_config &c = ctx->cfg;
@@ -980,7 +979,7 @@ int rt_present(rt_ctx *ctx, uint8_t *canvas) {
     hipLaunchKernelGGL(k_present, grid, dim3(256), 0, ctx->stream, ctx->d_rgba, c.width, c.height, c.supersampling, c.tr_method,
                        c.L_max, c.L_dmax, c.A, (float)ctx->Lbar, (float)ctx->sf, ctx->d_canvas);
     HIPCK(hipGetLastError());
-    HIPCK(hipMemcpyAsync(canvas, ctx->d_canvas, (size_t)c.width * c.height * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (canvas) HIPCK(hipMemcpyAsync(canvas, ctx->d_canvas, (size_t)c.width * c.height * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -996,6 +995,13 @@ int rt_device_float(rt_ctx *ctx, void **dptr, size_t *bytes) {
     if (!ctx) return -1;
     if (dptr) *dptr = ctx->d_fb;
     if (bytes) *bytes = (size_t)ctx->g.W * ctx->g.H * 3 * sizeof(float);
+    return 0;
+}
+
+int rt_device_canvas(rt_ctx *ctx, void **dptr, size_t *bytes) {
+    if (!ctx) return -1;
+    if (dptr) *dptr = ctx->d_canvas;
+    if (bytes) *bytes = (size_t)ctx->cfg.width * ctx->cfg.height * 4;
     return 0;
 }
 

@@ -1,0 +1,148 @@
+"""One process per GPU: tile-sharded frames over torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The path shards by image tiles with the scene replicated (every pixel is independent: the reference's
+fragment shader reads only uniforms and textures, js/8-kd_tree.js:1060-1069). Two exchange steps exist:
+  1. the log-average luminance is a whole-image statistic (js/8-kd_tree.js:2559-2568): each rank reduces
+     its own tiles to (sum log(EPS+L), pixel count) and the two numbers are all-reduced (SUM);
+  2. the finished RGBA8 tiles are gathered to rank 0, which scatters them into the full frame and runs the
+     present pass.
+The same FrameJob drives a CPU stand-in over gloo in the tests.
+"""
+import ctypes as C
+
+import numpy as np
+
+
+class Comm:
+    def __init__(self, rank, world, local_rank=0, backend="nccl"):
+        self.rank, self.world, self.local = rank, world, local_rank
+        self.dist = None
+        self.device = "cpu"
+        if backend == "nccl":
+            import torch
+            self.device = "cuda:%d" % local_rank
+        if world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def _reduce(self, value, dtype, op):
+        if not self.dist:
+            return value
+        import torch
+        t = torch.tensor([value], dtype=dtype, device=self.device)
+        self.dist.all_reduce(t, op=op)
+        return t.item()
+
+    def max_float(self, v):
+        import torch.distributed as dist
+        import torch
+        return self._reduce(float(v), torch.float64, dist.ReduceOp.MAX) if self.dist else v
+
+    def sum_int(self, v):
+        import torch.distributed as dist
+        import torch
+        return int(self._reduce(int(v), torch.int64, dist.ReduceOp.SUM)) if self.dist else v
+
+    def allreduce_tone(self, sum_log, count):
+        """(sum of log luminance, pixel count) summed over ranks; float64, so the count is exact to 2^53."""
+        if not self.dist:
+            return sum_log, count
+        import torch
+        t = torch.tensor([sum_log, float(count)], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t)
+        s, n = t.tolist()
+        return s, int(n)
+
+    def gather_bytes(self, shard, stride):
+        """Gathers every rank's `stride`-byte uint8 tensor to rank 0; returns one [world*stride] tensor there."""
+        import torch
+        if not self.dist:
+            return shard
+        out = None
+        if self.rank == 0:
+            out = torch.empty(self.world * stride, dtype=torch.uint8, device=shard.device)
+            parts = list(out.split(stride))
+        else:
+            parts = None
+        self.dist.gather(shard, gather_list=parts, dst=0)
+        return out
+
+    def close(self):
+        if self.dist and self.dist.is_initialized():
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+class _DevView:
+    """Zero-copy torch view of device memory owned by the HIP library."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class HipShard:
+    """Adapter: one RayTracerHIP context = one shard of the frame."""
+
+    def __init__(self, rt, device):
+        import torch
+        from . import abi
+        self.rt, self.torch, self.abi = rt, torch, abi
+        self.device = device
+        p, n = C.c_void_p(), C.c_size_t()
+        rt._ck(rt.L.rt_device_shard_rgba8(rt.ctx, C.byref(p), C.byref(n)), "rt_device_shard_rgba8")
+        self.compact = torch.as_tensor(_DevView(p.value, n.value), device=device)
+        g_tiles = ((rt.W + 7) // 8) * ((rt.H + 7) // 8)
+        sc = max(rt.cfg.shard_count, 1)
+        self.stride = ((g_tiles + sc - 1) // sc) * 256
+        self.staging = torch.zeros(self.stride, dtype=torch.uint8, device=device)
+
+    def trace(self):
+        self.rt.trace()
+
+    def tone_partial(self):
+        return self.rt.tonePartial()
+
+    def shard_bytes(self):
+        self.staging[:self.compact.numel()].copy_(self.compact)
+        return self.staging, self.stride
+
+    def assemble(self, gathered, stride, world):
+        self.torch.cuda.synchronize()
+        self.rt._ck(self.rt.L.rt_assemble_shards(self.rt.ctx, C.c_void_p(gathered.data_ptr()), C.c_size_t(stride), world),
+                    "rt_assemble_shards")
+
+    def tone_finish(self, s, n):
+        return self.rt.toneFinish(s, n)
+
+    def present(self):
+        self.rt._ck(self.rt.L.rt_present(self.rt.ctx, None), "rt_present")
+
+
+class FrameJob:
+    """One frame across all ranks: trace -> luminance all-reduce -> tile gather -> assemble -> present."""
+
+    def __init__(self, rt_or_shard, comm):
+        self.comm = comm
+        self.shard = rt_or_shard if hasattr(rt_or_shard, "tone_partial") else HipShard(rt_or_shard, comm.device)
+        self.Lbar = self.sf = None
+
+    def step(self):
+        sh, comm = self.shard, self.comm
+        sh.trace()
+        s, n = sh.tone_partial()
+        if comm.world > 1:
+            s, n = comm.allreduce_tone(s, n)
+            buf, stride = sh.shard_bytes()
+            gathered = comm.gather_bytes(buf, stride)
+            if comm.rank == 0:
+                sh.assemble(gathered, stride, comm.world)
+        self.Lbar, self.sf = sh.tone_finish(s, n)
+        if comm.rank == 0:
+            sh.present()
+        return self.Lbar, self.sf

@@ -68,7 +68,7 @@ def test_depth1_has_exactly_one_ray_per_pixel():
     _, _, ids, cn = o.trace(threads=2)
     assert cn.rays == 80 * 60 and cn.rays_level[1] == 0
     assert (ids >= 5).sum() > 100          # the bunny is in view (ids >= n_prims are faces)
-    assert cn.rays_in_box > 0 and cn.kd_steps > cn.kd_leaf_visits > 0
+    assert cn.rays_in_box[0] > 0 and cn.kd_steps[0] > cn.kd_leaf_visits[0] > 0
 
 
 def test_restart_traversal_equals_brute_force_over_listed_faces():
