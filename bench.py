@@ -82,12 +82,14 @@ def main():
     comm.barrier()
     torch.cuda.synchronize()
     lvl_ms = np.zeros(8)
+    stage_ms = np.zeros((8, 5))
     trace_ms = comp_ms = tone_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame.step()
         st = rt.stats()
         lvl_ms += np.array(list(st.level_kernel_ms))
+        stage_ms += np.array([list(r) for r in st.level_stage_ms])
         trace_ms += st.trace_ms
         comp_ms += st.composite_ms
         tone_ms += st.tone_ms
@@ -101,6 +103,7 @@ def main():
     per_level = [comm.sum_int(int(x)) for x in st.rays_per_level]
     K = args.steps
     lvl_ms /= K
+    stage_ms /= K
 
     if rank != 0:
         comm.close()
@@ -126,6 +129,10 @@ def main():
         "mshadow_rays_per_s": shadow / (dt / K) / 1e6,
         "trace_only_ms": trace_ms / K, "composite_ms": comp_ms / K, "tone_ms": tone_ms / K,
         "level_kernel_ms": [round(float(x), 4) for x in lvl_ms[:args.depth]],
+        "stage_names": ["k_gen_prims", "k_kd_walk<closest>", "k_shade_a", "k_kd_walk<any>", "k_shade_b"],
+        "level_stage_ms": [[round(float(x), 4) for x in row] for row in stage_ms[:args.depth]],
+        "stage_ms": [round(float(x), 4) for x in stage_ms.sum(axis=0)],
+        "kd_closest_rays": int(st.kd_closest_rays), "kd_shadow_rays": int(st.kd_shadow_rays),
         "kd_build_ms": st.kd_build_ms, "kd_upload_ms": st.kd_upload_ms, "scene_setup_s": setup_s,
     }
 

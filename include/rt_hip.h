@@ -103,7 +103,12 @@ typedef struct rt_stats {
     uint64_t shadow_rays;       /* lights x shaded nodes */
     uint64_t pixels;            /* pixels of this shard (supersampled resolution) */
     double   trace_ms;          /* device time of the whole trace (all levels + composite) */
-    double   level_kernel_ms[8];/* device time of the per-level trace kernel */
+    double   level_kernel_ms[8];/* device time of one level (all five stages) */
+    double   level_stage_ms[8][5]; /* per level: analytic closest hit, k-d closest-hit walk, shadow setup,
+                                      k-d any-hit walk, shading + spawn */
+    double   stage_ms[5];       /* the same, summed over levels */
+    uint64_t kd_closest_rays;   /* rays that walked the k-d tree for a closest hit */
+    uint64_t kd_shadow_rays;    /* shadow rays that walked the k-d tree */
     double   composite_ms;      /* device time of the bottom-up colour accumulation */
     double   tone_ms;           /* device time of the last rt_tone reduction */
     double   kd_build_ms;       /* host time of the last rt_build_kdtree */

@@ -258,9 +258,8 @@ __device__ __forceinline__ bool hit_prim(const SceneDev &S, const PrimDev &P, V3
 }
 
 // Moller-Trumbore as js/8-kd_tree.js:504-536 (two-sided, |det| < eps rejected, t < 0 rejected).
-__device__ __forceinline__ bool hit_tri(const TriDev &T, float tri_eps, V3 ro, V3 rd, float &t) {
-    V3 e1 = ld3(T.e1), e2 = ld3(T.e2);
-    V3 tv = ro - ld3(T.v0);
+__device__ __forceinline__ bool hit_tri_regs(V3 v0, V3 e1, V3 e2, float tri_eps, V3 ro, V3 rd, float &t) {
+    V3 tv = ro - v0;
     V3 P = cross(rd, e2), Q = cross(tv, e1);
     float det = dot(P, e1);
     if (fabsf(det) < tri_eps) return false;
@@ -270,6 +269,9 @@ __device__ __forceinline__ bool hit_tri(const TriDev &T, float tri_eps, V3 ro, V
     float u = inv * dot(P, tv), v = inv * dot(Q, rd);
     if (u < 0.0f || v < 0.0f || u + v > 1.0f) return false;
     return true;
+}
+__device__ __forceinline__ bool hit_tri(const TriDev &T, float tri_eps, V3 ro, V3 rd, float &t) {
+    return hit_tri_regs(ld3(T.v0), ld3(T.e1), ld3(T.e2), tri_eps, ro, rd, t);
 }
 
 // intersectRayAABB, js/8-kd_tree.js:545-573 (its boolean result is never used by the callers)
@@ -284,71 +286,6 @@ __device__ __forceinline__ void ray_box(const SceneDev &S, V3 ro, V3 rd, float &
         if (lo > tMin) tMin = lo;
         if (hi < tMax) tMax = hi;
     }
-}
-
-// k-d traversal. The reference restarts from the "pushed" node for every cell the ray crosses
-// (kd-pushdown, js/8-kd_tree.js:862-962); here the far child and the interval end are kept on a per-lane
-// stack in LDS instead, which visits exactly the same leaves in the same order with the same
-// comparisons: on a restart every ancestor decision is re-derived from the same plane distance t, the
-// same kdTMax and a kdTMin that only grew, so it repeats, and the first node to decide differently is the
-// one whose far child the stack holds. A NaN plane distance (0/0) ends the walk after the current leaf
-// in both forms (`kdTMax < maxDist` is false for NaN).
-// ANY = true: any-hit (castShadow), returns at the first triangle hit.
-// ANY = false: keeps the minimum t over every leaf crossed - no early exit, because a leaf keeps only
-// its first four faces and a later cell may list a triangle that an earlier, truncated cell dropped.
-template <bool ANY>
-__device__ __forceinline__ bool kd_walk(const SceneDev &S, V3 ro, V3 rd, uint2 *stack /* [KD_STACK][WAVE] slice */,
-                                        float &best_t, int32_t &best_face) {
-    float tmin, maxDist;
-    ray_box(S, ro, rd, tmin, maxDist);
-    if (!(tmin < maxDist)) return false;
-    const KdNodeDev *__restrict__ nodes = S.nodes;
-    uint32_t node = 0;
-    float tmax = maxDist;
-    int sp = 0;
-    for (;;) {
-        KdNodeDev n = nodes[node];
-        while ((n.info >> 30) == 1u) {
-            const int a = (int)((n.info >> 28) & 3u);
-            const float o = comp(ro, a), d = comp(rd, a);
-            const float t = (n.split - o) / d;
-            uint32_t nearc = n.info & 0x0fffffffu, farc = nearc + 1;
-            if (d <= 0.0f) { uint32_t tmp = nearc; nearc = farc; farc = tmp; }
-            if (t >= tmax) {
-                node = nearc;
-            } else if (t <= tmin) {
-                node = farc;
-            } else {
-                stack[sp * WAVE] = make_uint2(farc, __float_as_uint(tmax));
-                sp++;
-                node = nearc;
-                tmax = t;
-            }
-            n = nodes[node];
-        }
-        if ((n.info >> 30) == 3u) {
-            const KdLeafDev lf = S.leaves[n.info & 0x3fffffffu];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int32_t f = lf.face[i];
-                if (f > -1) {
-                    float t;
-                    if (hit_tri(S.tris[f], S.tri_eps, ro, rd, t)) {
-                        if (ANY) return true;
-                        if (t < best_t) { best_t = t; best_face = f; }
-                    }
-                }
-            }
-        }
-        if (!(tmax < maxDist)) break;   // also leaves on NaN
-        if (sp == 0) break;             // unreachable: tmax < maxDist implies a pending far child
-        sp--;
-        const uint2 e = stack[sp * WAVE];
-        node = e.x;
-        tmin = tmax;
-        tmax = __uint_as_float(e.y);
-    }
-    return false;
 }
 
 }  // namespace rt

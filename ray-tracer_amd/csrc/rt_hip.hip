@@ -1,14 +1,6 @@
 // C ABI (include/rt_hip.h) + the HIP kernels behind it. gfx950 only.
 //
-// Frame structure. The reference evaluates a per-pixel ray TREE inside one fragment-shader invocation
-// (js/8-kd_tree.js:822-1057): slot n spawns a reflected ray into slot 2n+1 and a refracted ray into
-// 2n+2, then colours are folded bottom-up. Here the tree is processed one LEVEL at a time over compact
-// ray queues: the level-k kernel traces and shades every level-k ray of the whole image and appends the
-// children it spawns to the level-(k+1) queue (wave-aggregated append: one atomic per wave, ranks from
-// the ballot). Each parent remembers the queue slots of its two children, and the composite pass then
-// folds colours level by level in the reference's order (refracted child first, then reflected:
-// js/8-kd_tree.js:1041-1054 walks the slots downwards, and 2n+2 > 2n+1), so the float result is the same
-// expression tree the shader evaluates.
+// Host side of the library: context, scene upload, per-frame orchestration of the kernels in rt_kernels.h.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -22,6 +14,7 @@
 #include "../../include/rt_hip.h"
 #include "kd_build.h"
 #include "rt_device.h"
+#include "rt_kernels.h"
 
 using namespace rt;
 
@@ -29,395 +22,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-// ------------------------------------------------------------------------------------------------
-// device-side queues
-struct LevelBuf {
-    float *ox, *oy, *oz, *dx, *dy, *dz;  // ray (unused at level 0: primary rays are generated)
-    float *cr, *cg, *cb;                 // local colour, later the folded colour
-    float *kr, *kt;                      // kReflect / kRefract of this node
-    int32_t *refl, *refr;                // queue slot of the child in the next level, -1 = none
-};
-
-struct FrameGeom {
-    int32_t W, H, tiles_x, n_tiles, shard_index, shard_count;
-};
-
-struct TraceArgs {
-    const SceneDev *S;
-    LevelBuf cur, nxt;
-    uint32_t n_rays;      // entries of `cur`
-    uint32_t nxt_cap;
-    uint32_t *nxt_count;
-    unsigned long long *shadow_count;
-    int32_t *hit_ids;     // level 0 only, full frame
-    FrameGeom g;
-    int32_t level, last_level;
-};
-
-__device__ __forceinline__ bool pixel_of(const FrameGeom &g, uint32_t tid, int &x, int &y) {
-    uint32_t tile = (uint32_t)g.shard_index + (tid >> 6) * (uint32_t)g.shard_count;
-    if (tile >= (uint32_t)g.n_tiles) return false;
-    uint32_t lane = tid & 63u;
-    x = (int)(tile % (uint32_t)g.tiles_x) * 8 + (int)(lane & 7u);
-    y = (int)(tile / (uint32_t)g.tiles_x) * 8 + (int)(lane >> 3);
-    return x < g.W && y < g.H;
-}
-
-__device__ __forceinline__ V3 mix3(V3 a, V3 b, float t) {
-    float s = 1.0f - t;
-    return v3(a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t);
-}
-
-// castShadow, js/8-kd_tree.js:575-714
-__device__ __forceinline__ bool in_shadow(const SceneDev &S, V3 ro, V3 rd, uint2 *stack) {
-    rd = normalize(rd);
-    for (int i = 0; i < S.n_prims; i++) {
-        PHit h;
-        if (hit_prim(S, S.prims[i], ro, rd, h)) return true;
-    }
-    if (S.render_triangles) {
-        if (S.use_kd) {
-            float bt = 0.0f;
-            int32_t bf = -1;
-            if (kd_walk<true>(S, ro, rd, stack, bt, bf)) return true;
-        } else {
-            for (int f = 0; f < S.n_faces; f++) {
-                float t;
-                if (hit_tri(S.tris[f], S.tri_eps, ro, rd, t)) return true;
-            }
-        }
-    }
-    return false;
-}
-
-struct Surface {
-    V3 point, normal, local;
-    int32_t mat;
-};
-
-// illuminate, js/8-kd_tree.js:716-820
-__device__ __forceinline__ V3 illuminate(const SceneDev &S, const Surface &sf, V3 rd, uint2 *stack, float &kReflect,
-                                         float &kRefract, float &ior) {
-    float ka = 0.0f, kd = 0.0f, ks = 0.0f, ke = 0.0f;
-    int mtype = -1;
-    V3 Co = v3(0, 0, 0), Cs = v3(0, 0, 0);
-    kReflect = kRefract = ior = 0.0f;
-    if (sf.mat >= 0) {
-        const MatDev &m = S.mats[sf.mat];
-        mtype = m.type;
-        ka = m.ka; kd = m.kd; ks = m.ks; ke = m.ke;
-        kReflect = m.kReflect; kRefract = m.kRefract; ior = m.ior;
-        Cs = ld3(m.Cs);
-        if (m.type == RT_MAT_PHONG_CHECKERED) {
-            float u = sf.local.x + 0.5f, v = sf.local.z + 0.5f;
-            float sizeU = 1.0f / 12.0f;
-            float sizeV = 450.0f / (1600.0f * 12.0f);
-            float row = (float)(int)(u / sizeU);
-            float col = (float)(int)(v / sizeV);
-            bool r0 = (int)glsl_mod(row, 2.0f) == 0, c0 = (int)glsl_mod(col, 2.0f) == 0;
-            Co = (r0 == c0) ? ld3(m.Co) : ld3(m.Co2);
-        } else {
-            Co = ld3(m.Co);
-        }
-    }
-    V3 N = normalize(sf.normal);
-    V3 V = normalize(-rd);
-    V3 ambient = mulv(ld3(S.ambient) * ka, Co);
-    V3 diffuse = v3(0, 0, 0), specular = v3(0, 0, 0);
-    for (int i = 0; i < S.n_lights; i++) {
-        V3 Lc = ld3(S.lights[i].col);
-        V3 Sd = normalize(ld3(S.lights[i].pos) - sf.point);
-        if (!in_shadow(S, sf.point + sf.normal * S.eps, Sd, stack)) {
-            float SdotN = fmaxf(0.0f, dot(Sd, N));
-            float dc = clamp01(kd * SdotN);
-            diffuse = diffuse + mulv(Lc * dc, Co);
-            if (SdotN > 0.0f) {
-                float sp = 0.0f;   // stays 0 for the checkered material (no branch assigns it)
-                if (mtype == RT_MAT_PHONG) {
-                    V3 I = -Sd;
-                    V3 R = normalize(I - N * (2.0f * dot(N, I)));
-                    sp = ks * pow_det(fmaxf(0.0f, dot(R, V)), ke);
-                } else if (mtype == RT_MAT_PHONG_BLINN) {
-                    V3 Hh = normalize(Sd + V);
-                    sp = ks * pow_det(fmaxf(0.0f, dot(N, Hh)), ke);
-                }
-                sp = clamp01(sp);
-                specular = specular + mulv(Lc * sp, Cs);
-            }
-        }
-    }
-    return v3(0, 0, 0) + ((ambient + specular) + diffuse);
-}
-
-__global__ __launch_bounds__(WAVE) void k_trace_level(TraceArgs A) {
-    __shared__ uint2 s_stack[KD_STACK * WAVE];
-    const SceneDev &S = *A.S;
-    const uint32_t tid = blockIdx.x * WAVE + threadIdx.x;
-    uint2 *stack = s_stack + threadIdx.x;
-
-    bool active;
-    V3 ro, rd;
-    int px = 0, py = 0;
-    if (A.level == 0) {
-        active = tid < A.n_rays && pixel_of(A.g, tid, px, py);
-        ro = ld3(S.cam);
-        float fx = ((float)px + 0.5f) / (float)A.g.W, fy = ((float)py + 0.5f) / (float)A.g.H;
-        V3 dir = mix3(mix3(ld3(S.r00), ld3(S.r01), fy), mix3(ld3(S.r10), ld3(S.r11), fy), fx);
-        rd = normalize(dir);
-    } else {
-        active = tid < A.n_rays;
-        uint32_t i = active ? tid : 0;
-        ro = v3(A.cur.ox[i], A.cur.oy[i], A.cur.oz[i]);
-        rd = v3(A.cur.dx[i], A.cur.dy[i], A.cur.dz[i]);
-    }
-
-    V3 color = v3(0, 0, 0);
-    float kReflect = 0.0f, kRefract = 0.0f, ior = 0.0f;
-    bool want_refl = false, want_refr = false, shaded = false;
-    V3 c_refl_o, c_refl_d, c_refr_o, c_refr_d;
-    c_refl_o = c_refl_d = c_refr_o = c_refr_d = v3(0, 0, 0);
-    int32_t hit_id = -1;
-
-    if (active) {
-        // ---- closest hit: analytic primitives in scene order, then the mesh (js/8-kd_tree.js:835-990)
-        float tMin = S.inf;
-        int32_t best_prim = -1, best_face = -1;
-        V3 b_nrm = v3(0, 0, 0), b_loc = v3(0, 0, 0), last_loc = v3(0, 0, 0);
-        for (int i = 0; i < S.n_prims; i++) {
-            PHit h;
-            if (hit_prim(S, S.prims[i], ro, rd, h)) {
-                last_loc = h.loc;   // HitInfo.localHitPoint keeps the last successful analytic test
-                if (h.t < tMin) {
-                    tMin = h.t;
-                    best_prim = i;
-                    b_nrm = h.nrm;
-                    b_loc = h.loc;
-                }
-            }
-        }
-        if (S.render_triangles) {
-            if (S.use_kd) {
-                kd_walk<false>(S, ro, rd, stack, tMin, best_face);
-            } else {
-                for (int f = 0; f < S.n_faces; f++) {
-                    float t;
-                    if (hit_tri(S.tris[f], S.tri_eps, ro, rd, t) && t < tMin) { tMin = t; best_face = f; }
-                }
-            }
-        }
-        if (best_prim < 0 && best_face < 0) {
-            color = ld3(S.bg);
-        } else {
-            Surface sf;
-            sf.point = ro + rd * tMin;
-            if (best_face >= 0) {
-                const TriDev &T = S.tris[best_face];
-                sf.normal = normalize(cross(ld3(T.e1), ld3(T.e2)));
-                sf.local = last_loc;   // intersectTriangle never writes localHitPoint (js/8-kd_tree.js:954)
-                sf.mat = T.mat;
-                hit_id = S.n_prims + best_face;
-            } else {
-                sf.normal = b_nrm;
-                sf.local = b_loc;
-                sf.mat = S.prims[best_prim].mat;
-                hit_id = best_prim;
-            }
-            shaded = true;
-            color = illuminate(S, sf, rd, stack, kReflect, kRefract, ior);
-            // ---- children (js/8-kd_tree.js:1010-1036); neither direction is normalised
-            if (!A.last_level) {
-                bool outside = dot(rd, sf.normal) < 0.0f;
-                V3 bias = sf.normal * S.eps;
-                if (kRefract > S.eps && ior > S.eps) {
-                    want_refr = true;
-                    c_refr_o = outside ? (sf.point - bias) : (sf.point + bias);
-                    V3 N = outside ? sf.normal : -sf.normal;
-                    float eta = outside ? (1.0f / ior) : ior;
-                    float cosi = dot(-N, rd);
-                    float k = 1.0f + eta * eta * (cosi * cosi - 1.0f);
-                    c_refr_d = rd * eta + N * (eta * cosi - sqrtf(k));
-                }
-                if (kReflect > S.eps) {
-                    want_refl = true;
-                    c_refl_o = outside ? (sf.point + bias) : (sf.point - bias);
-                    c_refl_d = rd - sf.normal * (2.0f * dot(sf.normal, rd));
-                }
-            }
-        }
-    }
-
-    // ---- wave-aggregated append of the children to the next level's queue
-    int32_t slot_refl = -1, slot_refr = -1;
-    if (!A.last_level) {
-        const unsigned long long m_refr = __ballot(want_refr), m_refl = __ballot(want_refl);
-        const uint32_t n_refr = (uint32_t)__popcll(m_refr), n_refl = (uint32_t)__popcll(m_refl);
-        if (n_refr + n_refl) {
-            uint32_t base = 0;
-            if (threadIdx.x == 0) base = atomicAdd(A.nxt_count, n_refr + n_refl);
-            base = __shfl(base, 0);
-            const unsigned long long below = (1ull << threadIdx.x) - 1ull;
-            if (want_refr) slot_refr = (int32_t)(base + (uint32_t)__popcll(m_refr & below));
-            if (want_refl) slot_refl = (int32_t)(base + n_refr + (uint32_t)__popcll(m_refl & below));
-            if (want_refr && (uint32_t)slot_refr < A.nxt_cap) {
-                A.nxt.ox[slot_refr] = c_refr_o.x; A.nxt.oy[slot_refr] = c_refr_o.y; A.nxt.oz[slot_refr] = c_refr_o.z;
-                A.nxt.dx[slot_refr] = c_refr_d.x; A.nxt.dy[slot_refr] = c_refr_d.y; A.nxt.dz[slot_refr] = c_refr_d.z;
-            } else {
-                slot_refr = -1;
-            }
-            if (want_refl && (uint32_t)slot_refl < A.nxt_cap) {
-                A.nxt.ox[slot_refl] = c_refl_o.x; A.nxt.oy[slot_refl] = c_refl_o.y; A.nxt.oz[slot_refl] = c_refl_o.z;
-                A.nxt.dx[slot_refl] = c_refl_d.x; A.nxt.dy[slot_refl] = c_refl_d.y; A.nxt.dz[slot_refl] = c_refl_d.z;
-            } else {
-                slot_refl = -1;
-            }
-        }
-    }
-    const unsigned long long m_sh = __ballot(shaded);
-    if (m_sh && threadIdx.x == 0) atomicAdd(A.shadow_count, (unsigned long long)__popcll(m_sh) * (unsigned long long)S.n_lights);
-
-    if (tid < A.n_rays) {
-        A.cur.cr[tid] = color.x; A.cur.cg[tid] = color.y; A.cur.cb[tid] = color.z;
-        A.cur.kr[tid] = kReflect; A.cur.kt[tid] = kRefract;
-        A.cur.refl[tid] = slot_refl; A.cur.refr[tid] = slot_refr;
-        if (A.level == 0 && active && A.hit_ids) A.hit_ids[(size_t)py * A.g.W + px] = hit_id;
-    }
-}
-
-// parent.color += kRefract * refracted.color, then += kReflect * reflected.color (js/8-kd_tree.js:1041-1054)
-__global__ __launch_bounds__(256) void k_composite(LevelBuf cur, LevelBuf nxt, uint32_t n) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float r = cur.cr[i], g = cur.cg[i], b = cur.cb[i];
-    int32_t c = cur.refr[i];
-    if (c >= 0) {
-        float k = cur.kt[i];
-        r = r + k * nxt.cr[c]; g = g + k * nxt.cg[c]; b = b + k * nxt.cb[c];
-    }
-    c = cur.refl[i];
-    if (c >= 0) {
-        float k = cur.kr[i];
-        r = r + k * nxt.cr[c]; g = g + k * nxt.cg[c]; b = b + k * nxt.cb[c];
-    }
-    cur.cr[i] = r; cur.cg[i] = g; cur.cb[i] = b;
-}
-
-__device__ __forceinline__ uint32_t quant8(float c) {   // GL float -> unorm8: round(clamp(c,0,1)*255)
-    if (!(c == c)) return 0u;
-    return (uint32_t)(int)(clamp01(c) * 255.0f + 0.5f);
-}
-
-// level-0 colours -> float target, RGBA8 target (both full-frame, bottom-up rows) and the shard-compact
-// RGBA8 copy (tile order; alpha 0 marks lanes that fall outside the image)
-__global__ __launch_bounds__(256) void k_resolve(LevelBuf l0, uint32_t n, FrameGeom g, float *fb, uint32_t *rgba,
-                                                 uint32_t *compact) {
-    uint32_t tid = blockIdx.x * 256 + threadIdx.x;
-    if (tid >= n) return;
-    int x, y;
-    if (!pixel_of(g, tid, x, y)) { compact[tid] = 0u; return; }
-    float r = l0.cr[tid], gg = l0.cg[tid], b = l0.cb[tid];
-    size_t p = (size_t)y * g.W + x;
-    fb[3 * p] = r; fb[3 * p + 1] = gg; fb[3 * p + 2] = b;
-    uint32_t v = quant8(r) | (quant8(gg) << 8) | (quant8(b) << 16) | 0xff000000u;
-    rgba[p] = v;
-    compact[tid] = v;
-}
-
-// sum over this shard of log(EPSILON + L), L = 0.27 r + 0.67 g + 0.07 b with r = byte * L_MAX / 256
-// (js/8-kd_tree.js:2561-2566), double precision. Two deterministic stages: per-block partials, then one block.
-__global__ __launch_bounds__(256) void k_tone_partial(const uint32_t *compact, uint32_t n, double L_max, double *part_sum,
-                                                      unsigned long long *part_cnt) {
-    __shared__ double s_sum[4];
-    __shared__ unsigned long long s_cnt[4];
-    double acc = 0.0;
-    unsigned long long cnt = 0;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        uint32_t v = compact[i];
-        if (v >> 24) {
-            double r = (double)(v & 255u) * L_max / 256.0;
-            double g = (double)((v >> 8) & 255u) * L_max / 256.0;
-            double b = (double)((v >> 16) & 255u) * L_max / 256.0;
-            double L = 0.27 * r + 0.67 * g + 0.07 * b;
-            acc += log(0.0001 + L);
-            cnt++;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        acc += __shfl_down(acc, o);
-        cnt += __shfl_down(cnt, o);
-    }
-    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = acc; s_cnt[threadIdx.x >> 6] = cnt; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        part_sum[blockIdx.x] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
-        part_cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    }
-}
-
-__global__ __launch_bounds__(64) void k_tone_final(const double *part_sum, const unsigned long long *part_cnt, int n_parts,
-                                                   double *out_sum, unsigned long long *out_cnt) {
-    double acc = 0.0;
-    unsigned long long cnt = 0;
-    for (int i = threadIdx.x; i < n_parts; i += 64) { acc += part_sum[i]; cnt += part_cnt[i]; }
-    for (int o = 32; o > 0; o >>= 1) {
-        acc += __shfl_down(acc, o);
-        cnt += __shfl_down(cnt, o);
-    }
-    if (threadIdx.x == 0) { *out_sum = acc; *out_cnt = cnt; }
-}
-
-// Present pass, js/8-kd_tree.js:85-143: S x S NEAREST taps (offsets divide by 800*S / 600*S, the WIDTH and
-// HEIGHT the reference script holds when it builds the shader string, js/8-kd_tree.js:55,110-111), scale by
-// L_MAX, Ward (x sf) or Reinhard, divide by L_DMAX, quantise.
-__global__ __launch_bounds__(256) void k_present(const uint32_t *rgba, int W, int H, int S, int method, float L_max,
-                                                 float L_dmax, float Akey, float Lbar, float sf, uint32_t *canvas) {
-    int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (x >= W || y >= H) return;
-    const int TW = W * S, TH = H * S;
-    const float offW = (float)(800 * S), offH = (float)(600 * S);
-    float tx = ((float)x + 0.5f) / (float)W, ty = ((float)y + 0.5f) / (float)H;
-    float lo, hi;
-    if (glsl_mod((float)S, 2.0f) > 0.0f) { lo = (float)(-(S / 2)); hi = (float)(S / 2); }
-    else { float e = (float)(S / 2) - 0.5f; lo = -e; hi = e; }
-    float acc[3] = {0.0f, 0.0f, 0.0f};
-    for (float i = lo; i <= hi; i += 1.0f)
-        for (float j = lo; j <= hi; j += 1.0f) {
-            float cx = clamp01(tx + i / offW), cy = clamp01(ty + j / offH);
-            int sx = (int)floorf(cx * (float)TW), sy = (int)floorf(cy * (float)TH);
-            sx = sx > TW - 1 ? TW - 1 : sx;
-            sy = sy > TH - 1 ? TH - 1 : sy;
-            uint32_t v = rgba[(size_t)sy * TW + sx];
-            acc[0] += (float)(v & 255u) / 255.0f;
-            acc[1] += (float)((v >> 8) & 255u) / 255.0f;
-            acc[2] += (float)((v >> 16) & 255u) / 255.0f;
-        }
-    uint32_t out = 0xff000000u;
-    for (int k = 0; k < 3; k++) {
-        float c = acc[k] / (float)(S * S);
-        c *= L_max;
-        if (method == 0) {
-            c *= sf;
-        } else {
-            c = c * Akey / Lbar;
-            c = c * L_dmax / (1.0f + c);
-        }
-        c /= L_dmax;
-        out |= quant8(c) << (8 * k);
-    }
-    canvas[(size_t)y * W + x] = out;
-}
-
-// scatter gathered shard-compact buffers (each `stride` pixels long) into the full-frame RGBA8 target
-__global__ __launch_bounds__(256) void k_assemble(const uint32_t *gathered, uint32_t stride, int n_shards, FrameGeom g,
-                                                  uint32_t *rgba) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= stride * (uint32_t)n_shards) return;
-    FrameGeom gs = g;
-    gs.shard_index = (int)(i / stride);
-    gs.shard_count = n_shards;
-    int x, y;
-    if (!pixel_of(gs, i % stride, x, y)) return;
-    rgba[(size_t)y * g.W + x] = gathered[i];
-}
+constexpr int N_STAGES = 5;   // k_gen_prims, k_kd_walk<closest>, k_shade_a, k_kd_walk<any>, k_shade_b
 
 // ------------------------------------------------------------------------------------------------
 struct Level {
@@ -432,7 +37,9 @@ struct rt_ctx {
     rt_config cfg{};
     std::string err;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[2 * MAX_LEVELS + 4]{};
+    hipEvent_t ev[MAX_LEVELS][N_STAGES + 1]{};   // stage boundaries of every level
+    hipEvent_t ev_misc[4]{};                     // frame begin / composite begin / frame end / spare
+    int n_cus = 256;
     // scene (host copies)
     std::vector<PrimDev> prims;
     std::vector<rt_material> mats_host;
@@ -454,8 +61,12 @@ struct rt_ctx {
     KdLeafDev *d_leaves = nullptr;
     size_t cap_prims = 0, cap_mats = 0, cap_lights = 0, cap_tris = 0, cap_nodes = 0, cap_leaves = 0;
     Level lv[MAX_LEVELS];
-    uint32_t *d_counts = nullptr;                // per-level ray counts
-    unsigned long long *d_shadow = nullptr;
+    LevelCounters *d_counts = nullptr;           // one block of counters per level
+    uint32_t *d_kdq = nullptr;                   // closest-hit traversal queue (ray indices), reused by every level
+    void *d_shq_mem = nullptr;                   // shadow traversal queue, reused by every level
+    ShadowQ shq{};
+    size_t cap_kdq = 0;
+    uint32_t cap_shq = 0;
     uint32_t n_rays[MAX_LEVELS]{};
     // frame
     FrameGeom g{};
@@ -505,13 +116,34 @@ int ensure_level(rt_ctx *ctx, int l, uint32_t cap) {
     if (L.mem) HIPCK(hipFree(L.mem));
     L.mem = nullptr;
     cap = std::max<uint32_t>((cap + 255u) & ~255u, 256u);
-    HIPCK(hipMalloc(&L.mem, (size_t)cap * 13 * sizeof(float)));
+    HIPCK(hipMalloc(&L.mem, (size_t)cap * LEVEL_ARRAYS * sizeof(float)));
     L.cap = cap;
     float *p = (float *)L.mem;
-    float **f[] = {&L.b.ox, &L.b.oy, &L.b.oz, &L.b.dx, &L.b.dy, &L.b.dz, &L.b.cr, &L.b.cg, &L.b.cb, &L.b.kr, &L.b.kt};
+    float **f[] = {&L.b.ox, &L.b.oy, &L.b.oz, &L.b.dx, &L.b.dy, &L.b.dz, &L.b.ht, &L.b.cr, &L.b.cg, &L.b.cb, &L.b.kr, &L.b.kt};
     for (auto q : f) { *q = p; p += cap; }
+    L.b.hp = (uint32_t *)p; p += cap;
+    L.b.hf = (int32_t *)p; p += cap;
+    L.b.shadow = (uint32_t *)p; p += cap;
     L.b.refl = (int32_t *)p; p += cap;
     L.b.refr = (int32_t *)p;
+    return 0;
+}
+
+// traversal queues are shared by all levels: sized for the largest level seen so far
+int ensure_queues(rt_ctx *ctx, uint32_t n_rays, uint32_t n_lights) {
+    if (ensure(ctx, ctx->d_kdq, ctx->cap_kdq, n_rays)) return -1;
+    uint64_t want = (uint64_t)n_rays * std::max<uint32_t>(n_lights, 1);
+    if (want > 0x7fffff00ull) return fail(ctx, "shadow queue too large");
+    if (ctx->d_shq_mem && ctx->cap_shq >= want) return 0;
+    if (ctx->d_shq_mem) HIPCK(hipFree(ctx->d_shq_mem));
+    ctx->d_shq_mem = nullptr;
+    uint32_t cap = std::max<uint32_t>(((uint32_t)want + 255u) & ~255u, 256u);
+    HIPCK(hipMalloc(&ctx->d_shq_mem, (size_t)cap * SHADOWQ_ARRAYS * sizeof(float)));
+    ctx->cap_shq = cap;
+    float *p = (float *)ctx->d_shq_mem;
+    float **f[] = {&ctx->shq.ox, &ctx->shq.oy, &ctx->shq.oz, &ctx->shq.dx, &ctx->shq.dy, &ctx->shq.dz};
+    for (auto q : f) { *q = p; p += cap; }
+    ctx->shq.id = (uint32_t *)p;
     return 0;
 }
 
@@ -641,8 +273,16 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     hipError_t e;
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) return bail("hipStreamCreate", e);
-    for (auto &ev : ctx->ev)
+    for (auto &row : ctx->ev)
+        for (auto &ev : row)
+            if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    for (auto &ev : ctx->ev_misc)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    {
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+        ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     FrameGeom &g = ctx->g;
     g.W = cfg->width * cfg->supersampling;
     g.H = cfg->height * cfg->supersampling;
@@ -662,8 +302,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     ALLOC(ctx->d_hit, npx * 4);
     ALLOC(ctx->d_compact, std::max<size_t>(ctx->n0, 64) * 4);
     ALLOC(ctx->d_canvas, (size_t)cfg->width * cfg->height * 4);
-    ALLOC(ctx->d_counts, MAX_LEVELS * sizeof(uint32_t));
-    ALLOC(ctx->d_shadow, sizeof(unsigned long long));
+    ALLOC(ctx->d_counts, MAX_LEVELS * sizeof(LevelCounters));
     ALLOC(ctx->d_part_sum, TONE_BLOCKS * sizeof(double));
     ALLOC(ctx->d_part_cnt, TONE_BLOCKS * sizeof(unsigned long long));
     ALLOC(ctx->d_tone_out, sizeof(double));
@@ -679,13 +318,16 @@ void rt_destroy(rt_ctx *ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->d_scene, ctx->d_prims, ctx->d_mats, ctx->d_lights, ctx->d_tris, ctx->d_nodes, ctx->d_leaves,
-                    ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_canvas, ctx->d_counts, ctx->d_shadow,
-                    ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt};
+                    ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_canvas, ctx->d_counts, ctx->d_kdq,
+                    ctx->d_shq_mem, ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &l : ctx->lv)
         if (l.mem) (void)hipFree(l.mem);
-    for (auto &ev : ctx->ev)
+    for (auto &row : ctx->ev)
+        for (auto &ev : row)
+            if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : ctx->ev_misc)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -694,6 +336,7 @@ void rt_destroy(rt_ctx *ctx) {
 int rt_set_primitives(rt_ctx *ctx, const rt_prim *prims, int32_t n) {
     if (!ctx) return -1;
     if (n < 0 || (n > 0 && !prims)) return fail(ctx, "rt_set_primitives: bad arguments");
+    if (n > 60000) return fail(ctx, "rt_set_primitives: at most 60000 primitives");
     for (int i = 0; i < n; i++)
         if (prims[i].kind < RT_PRIM_PLANE || prims[i].kind > RT_PRIM_CYLINDER) return fail(ctx, "rt_set_primitives: unknown primitive kind");
     ctx->prims_host.assign(prims, prims + n);
@@ -715,6 +358,7 @@ int rt_set_materials(rt_ctx *ctx, const rt_material *mats, int32_t n) {
 int rt_set_lights(rt_ctx *ctx, const rt_light *lights, int32_t n, int32_t n_loop) {
     if (!ctx) return -1;
     if (n < 0 || (n > 0 && !lights) || n_loop < n) return fail(ctx, "rt_set_lights: bad arguments (need n >= 0, n_loop >= n)");
+    if (n_loop > MAX_LIGHTS) return fail(ctx, "rt_set_lights: at most 32 lights");
     ctx->lights.assign((size_t)n_loop, LightDev{{0, 0, 0, 0}, {0, 0, 0, 0}});
     for (int i = 0; i < n; i++)
         for (int k = 0; k < 3; k++) { ctx->lights[i].pos[k] = lights[i].position[k]; ctx->lights[i].col[k] = lights[i].color[k]; }
@@ -806,14 +450,17 @@ int rt_trace(rt_ctx *ctx) {
     HIPCK(hipSetDevice(ctx->cfg.device));
     if (ctx->scene_dirty && upload_scene(ctx)) return -1;
     const int D = ctx->cfg.max_depth;
+    const SceneDev &sh = ctx->sh;
+    const bool walk = sh.render_triangles && sh.use_kd;
     hipStream_t s = ctx->stream;
-    HIPCK(hipMemsetAsync(ctx->d_counts, 0, MAX_LEVELS * sizeof(uint32_t), s));
-    HIPCK(hipMemsetAsync(ctx->d_shadow, 0, sizeof(unsigned long long), s));
+    HIPCK(hipMemsetAsync(ctx->d_counts, 0, MAX_LEVELS * sizeof(LevelCounters), s));
     memset(ctx->n_rays, 0, sizeof ctx->n_rays);
     ctx->n_rays[0] = ctx->n0;
     if (ensure_level(ctx, 0, ctx->n0)) return -1;
-    hipEvent_t ev_begin = ctx->ev[2 * MAX_LEVELS], ev_end = ctx->ev[2 * MAX_LEVELS + 1], ev_comp = ctx->ev[2 * MAX_LEVELS + 2];
+    hipEvent_t ev_begin = ctx->ev_misc[0], ev_comp = ctx->ev_misc[1], ev_end = ctx->ev_misc[2];
     HIPCK(hipEventRecord(ev_begin, s));
+    // persistent traversal waves: one 64-lane workgroup each, 8.8 KB of LDS (short stack, rays, FIFO) -> 18 fit a CU
+    const dim3 walk_grid((unsigned)ctx->n_cus * (unsigned)RT_WALK_WAVES_PER_CU);
     int levels_run = 0;
     for (int l = 0; l < D; l++) {
         const uint32_t n = ctx->n_rays[l];
@@ -823,25 +470,39 @@ int rt_trace(rt_ctx *ctx) {
             uint64_t want = std::min<uint64_t>(2ull * n, 0x7fffff00ull);
             if (ensure_level(ctx, l + 1, (uint32_t)want)) return -1;
         }
-        TraceArgs A{};
-        A.S = ctx->d_scene;
+        if (ensure_queues(ctx, n, (uint32_t)sh.n_lights)) return -1;
+        LevelArgs A{};
+        A.S = ctx->sh;
         A.cur = ctx->lv[l].b;
         if (!last) { A.nxt = ctx->lv[l + 1].b; A.nxt_cap = ctx->lv[l + 1].cap; }
+        A.shq = ctx->shq;
+        A.shq_cap = ctx->cap_shq;
+        A.kdq = ctx->d_kdq;
+        A.cnt = ctx->d_counts + l;
         A.n_rays = n;
-        A.nxt_count = ctx->d_counts + (l + 1 < MAX_LEVELS ? l + 1 : 0);
-        A.shadow_count = ctx->d_shadow;
         A.hit_ids = ctx->d_hit;
         A.g = ctx->g;
         A.level = l;
         A.last_level = last ? 1 : 0;
-        HIPCK(hipEventRecord(ctx->ev[2 * l], s));
-        hipLaunchKernelGGL(k_trace_level, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, A);
+        WalkArgs Wk{ctx->sh, ctx->lv[l].b, ctx->shq, ctx->d_kdq, ctx->d_counts + l, ctx->cap_shq};
+        const dim3 grid((n + BLOCK - 1) / BLOCK);
+        hipEvent_t *ev = ctx->ev[l];
+        HIPCK(hipEventRecord(ev[0], s));
+        hipLaunchKernelGGL(k_gen_prims, grid, dim3(BLOCK), 0, s, A);
+        HIPCK(hipEventRecord(ev[1], s));
+        if (walk) hipLaunchKernelGGL(k_kd_walk<false>, walk_grid, dim3(WAVE), 0, s, Wk);
+        HIPCK(hipEventRecord(ev[2], s));
+        hipLaunchKernelGGL(k_shade_a, grid, dim3(BLOCK), 0, s, A);
+        HIPCK(hipEventRecord(ev[3], s));
+        if (walk) hipLaunchKernelGGL(k_kd_walk<true>, walk_grid, dim3(WAVE), 0, s, Wk);
+        HIPCK(hipEventRecord(ev[4], s));
+        hipLaunchKernelGGL(k_shade_b, grid, dim3(BLOCK), 0, s, A);
         HIPCK(hipGetLastError());
-        HIPCK(hipEventRecord(ctx->ev[2 * l + 1], s));
+        HIPCK(hipEventRecord(ev[5], s));
         levels_run = l + 1;
         if (!last) {
             uint32_t cnt = 0;
-            HIPCK(hipMemcpyAsync(&cnt, ctx->d_counts + l + 1, sizeof cnt, hipMemcpyDeviceToHost, s));
+            HIPCK(hipMemcpyAsync(&cnt, &ctx->d_counts[l].next_count, sizeof cnt, hipMemcpyDeviceToHost, s));
             HIPCK(hipStreamSynchronize(s));
             ctx->n_rays[l + 1] = std::min(cnt, ctx->lv[l + 1].cap);
         }
@@ -856,16 +517,23 @@ int rt_trace(rt_ctx *ctx) {
                        ctx->d_rgba, ctx->d_compact);
     HIPCK(hipGetLastError());
     HIPCK(hipEventRecord(ev_end, s));
-    unsigned long long sh = 0;
-    HIPCK(hipMemcpyAsync(&sh, ctx->d_shadow, sizeof sh, hipMemcpyDeviceToHost, s));
+    LevelCounters hc[MAX_LEVELS];
+    HIPCK(hipMemcpyAsync(hc, ctx->d_counts, sizeof hc, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
 
-    rt_stats &st = ctx->st;
-    st.rays_total = 0;
-    memset(st.rays_per_level, 0, sizeof st.rays_per_level);
-    memset(st.level_kernel_ms, 0, sizeof st.level_kernel_ms);
-    // level 0 holds whole tiles; lanes outside the image are not rays
+#if defined(RT_DBG_COUNT)
     {
+        unsigned long long d[16] = {0};
+        for (int l = 0; l < levels_run; l++) for (int k = 0; k < 16; k++) d[k] += hc[l].dbg[k];
+        const char *names[8] = {"wave_iters", "lane_actions", "batches", "pairs", "refills", "restarts", "leaf_actions", "emit_iters"};
+        for (int k = 0; k < 8; k++) fprintf(stderr, "DBG %-12s closest %14llu  any %14llu\n", names[k], d[k], d[8 + k]);
+    }
+#endif
+    rt_stats &st = ctx->st;
+    const double keep_build = st.kd_build_ms, keep_upload = st.kd_upload_ms, keep_tone = st.tone_ms;
+    memset(&st, 0, sizeof st);
+    st.kd_build_ms = keep_build; st.kd_upload_ms = keep_upload; st.tone_ms = keep_tone;
+    {   // level 0 holds whole tiles; lanes outside the image are not rays
         uint64_t px = 0;
         const FrameGeom &g = ctx->g;
         for (int t = g.shard_index; t < g.n_tiles; t += g.shard_count) {
@@ -878,11 +546,18 @@ int rt_trace(rt_ctx *ctx) {
     for (int l = 1; l < levels_run; l++) st.rays_per_level[l] = ctx->n_rays[l];
     for (int l = 0; l < levels_run; l++) {
         st.rays_total += st.rays_per_level[l];
+        st.shadow_rays += (uint64_t)hc[l].shaded * (uint64_t)sh.n_lights;
+        st.kd_closest_rays += hc[l].kdq_count;
+        st.kd_shadow_rays += hc[l].shq_count;
         float ms = 0;
-        HIPCK(hipEventElapsedTime(&ms, ctx->ev[2 * l], ctx->ev[2 * l + 1]));
+        for (int k = 0; k < N_STAGES; k++) {
+            HIPCK(hipEventElapsedTime(&ms, ctx->ev[l][k], ctx->ev[l][k + 1]));
+            st.level_stage_ms[l][k] = ms;
+            st.stage_ms[k] += ms;
+        }
+        HIPCK(hipEventElapsedTime(&ms, ctx->ev[l][0], ctx->ev[l][N_STAGES]));
         st.level_kernel_ms[l] = ms;
     }
-    st.shadow_rays = sh;
     float ms = 0;
     HIPCK(hipEventElapsedTime(&ms, ev_begin, ev_end));
     st.trace_ms = ms;
@@ -929,7 +604,7 @@ int rt_tone_partial(rt_ctx *ctx, double *sum_log, uint64_t *count) {
     if (!ctx->traced) return fail(ctx, "rt_tone_partial: nothing traced yet");
     HIPCK(hipSetDevice(ctx->cfg.device));
     hipStream_t s = ctx->stream;
-    hipEvent_t e0 = ctx->ev[2 * MAX_LEVELS], e1 = ctx->ev[2 * MAX_LEVELS + 1];
+    hipEvent_t e0 = ctx->ev_misc[0], e1 = ctx->ev_misc[3];
     HIPCK(hipEventRecord(e0, s));
     int blocks = (int)std::min<uint32_t>((ctx->n0 + 255) / 256, TONE_BLOCKS);
     if (blocks < 1) blocks = 1;
