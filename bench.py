@@ -82,7 +82,7 @@ def main():
     comm.barrier()
     torch.cuda.synchronize()
     lvl_ms = np.zeros(8)
-    stage_ms = np.zeros((8, 5))
+    stage_ms = np.zeros((8, 7))
     trace_ms = comp_ms = tone_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -129,7 +129,8 @@ def main():
         "mshadow_rays_per_s": shadow / (dt / K) / 1e6,
         "trace_only_ms": trace_ms / K, "composite_ms": comp_ms / K, "tone_ms": tone_ms / K,
         "level_kernel_ms": [round(float(x), 4) for x in lvl_ms[:args.depth]],
-        "stage_names": ["k_gen_prims", "k_kd_walk<closest>", "k_shade_a", "k_kd_walk<any>", "k_shade_b"],
+        "stage_names": ["k_gen_prims", "k_kd_walk<closest>", "k_tri_test<closest>", "k_shade_a", "k_kd_walk<shadow>", "k_tri_test<shadow>", "k_shade_b"],
+        "tri_records": [int(x) for x in st.tri_records],
         "level_stage_ms": [[round(float(x), 4) for x in row] for row in stage_ms[:args.depth]],
         "stage_ms": [round(float(x), 4) for x in stage_ms.sum(axis=0)],
         "kd_closest_rays": int(st.kd_closest_rays), "kd_shadow_rays": int(st.kd_shadow_rays),

@@ -103,10 +103,11 @@ typedef struct rt_stats {
     uint64_t shadow_rays;       /* lights x shaded nodes */
     uint64_t pixels;            /* pixels of this shard (supersampled resolution) */
     double   trace_ms;          /* device time of the whole trace (all levels + composite) */
-    double   level_kernel_ms[8];/* device time of one level (all five stages) */
-    double   level_stage_ms[8][5]; /* per level: analytic closest hit, k-d closest-hit walk, shadow setup,
-                                      k-d any-hit walk, shading + spawn */
-    double   stage_ms[5];       /* the same, summed over levels */
+    double   level_kernel_ms[8];/* device time of one level (all seven stages) */
+    double   level_stage_ms[8][7]; /* per level: analytic closest hit, k-d walk (closest), triangle tests (closest),
+                                      shadow setup, k-d walk (shadow), triangle tests (shadow), shading + spawn */
+    double   stage_ms[7];       /* the same, summed over levels */
+    uint64_t tri_records[2];    /* (ray, triangle) records listed by the closest / shadow walks */
     uint64_t kd_closest_rays;   /* rays that walked the k-d tree for a closest hit */
     uint64_t kd_shadow_rays;    /* shadow rays that walked the k-d tree */
     double   composite_ms;      /* device time of the bottom-up colour accumulation */

@@ -62,7 +62,7 @@ class Counters(C.Structure):
                 ("kd_steps", A8), ("kd_leaf_visits", A8), ("kd_tri_tests", A8),
                 ("shadow_level", A8), ("shadow_in_box", A8),
                 ("sh_steps", A8), ("sh_leaf_visits", A8), ("sh_tri_tests", A8),
-                ("prim_tests", A8), ("sh_prim_tests", A8)]
+                ("prim_tests", A8), ("sh_prim_tests", A8), ("sh_mesh_hits", C.c_uint64), ("sh_hit_after_leaves", A8)]
 
     def algorithmic(self, level=None):
         """Bytes and flops the REFERENCE algorithm moves/does for the counted rays: per ray

@@ -75,6 +75,8 @@ typedef struct oracle_counters {
     uint64_t sh_steps[8], sh_leaf_visits[8], sh_tri_tests[8];       /* any-hit traversal */
     uint64_t prim_tests[8];         /* analytic primitive tests of closest-hit rays */
     uint64_t sh_prim_tests[8];      /* analytic primitive tests of shadow rays */
+    uint64_t sh_mesh_hits;          /* shadow rays stopped by a mesh triangle */
+    uint64_t sh_hit_after_leaves[8];/* of those: non-empty leaves visited up to the hit: 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, 65+ */
 } oracle_counters;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -333,6 +335,7 @@ static int kdTraverse(const oracle_scene *sc, f3 ro, f3 rd, HitInfo *h, int clos
     f3 pushedBoxMax = F3(sc->kd_box_max[0], sc->kd_box_max[1], sc->kd_box_max[2]);
     int pushedDepth = 0;
     int entered = 0;
+    uint64_t leaves_seen = 0;
     if ((pushedNode >> 30) != RT_KD_INVALID) {
         int pushdown = 1;
         while (kdTMax < maxDist) {
@@ -381,6 +384,7 @@ static int kdTraverse(const oracle_scene *sc, f3 ro, f3 rd, HitInfo *h, int clos
             }
             if ((currNode >> 30) != RT_KD_EMPTY_LEAF) {
                 if (closest) cn->kd_leaf_visits[lv]++; else cn->sh_leaf_visits[lv]++;
+                leaves_seen++;
                 const int32_t *fi = sc->kd_leaves + 4 * (size_t)(currNode & 0x3fffffffu);
                 for (int i = 0; i < 4; i++) {
                     if (fi[i] > -1) {
@@ -388,7 +392,14 @@ static int kdTraverse(const oracle_scene *sc, f3 ro, f3 rd, HitInfo *h, int clos
                         fetchTri(sc, fi[i], tv);
                         if (closest) cn->kd_tri_tests[lv]++; else cn->sh_tri_tests[lv]++;
                         if (!closest) {
-                            if (intersectTriangle(sc, ro, rd, h, tv)) return 1;
+                            if (intersectTriangle(sc, ro, rd, h, tv)) {
+                                int b = leaves_seen <= 1 ? 0 : leaves_seen <= 2 ? 1 : leaves_seen <= 4 ? 2 : leaves_seen <= 8 ? 3 :
+                                        leaves_seen <= 16 ? 4 : leaves_seen <= 32 ? 5 : leaves_seen <= 64 ? 6 : 7;
+                                cn->sh_mesh_hits++;
+                                cn->sh_hit_after_leaves[b]++;
+                                if (entered) cn->shadow_in_box[lv]++;
+                                return 1;
+                            }
                         } else if (intersectTriangle(sc, ro, rd, h, tv) && h->t < best->tMin) {
                             h->hit = 1;
                             best->hitPoint = add3(ro, mul3(rd, h->t));

@@ -43,7 +43,7 @@ class Light(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_total", C.c_uint64), ("rays_per_level", C.c_uint64 * 8), ("shadow_rays", C.c_uint64),
                 ("pixels", C.c_uint64), ("trace_ms", C.c_double), ("level_kernel_ms", C.c_double * 8),
-                ("level_stage_ms", (C.c_double * 5) * 8), ("stage_ms", C.c_double * 5),
+                ("level_stage_ms", (C.c_double * 7) * 8), ("stage_ms", C.c_double * 7), ("tri_records", C.c_uint64 * 2),
                 ("kd_closest_rays", C.c_uint64), ("kd_shadow_rays", C.c_uint64),
                 ("composite_ms", C.c_double), ("tone_ms", C.c_double), ("kd_build_ms", C.c_double),
                 ("kd_upload_ms", C.c_double)]

@@ -9,6 +9,7 @@
 #include <utility>
 
 namespace rt {
+void relayout_treelets(KdTreeHost &t);
 namespace {
 
 struct BoxD { double lo[3], hi[3]; };
@@ -269,14 +270,77 @@ void build_kdtree(const double *verts, int64_t n_verts, const uint32_t *faces, i
         out.n_internal += A.n_internal; out.n_leaf += A.n_leaf; out.n_empty += A.n_empty;
     }
     for (int k = 0; k < 3; k++) { out.root_box[k] = rb.lo[k]; out.root_box[3 + k] = rb.hi[k]; }
+    out.n_nodes = (int64_t)out.nodes.size();
+    relayout_treelets(out);
+}
+
+// Re-orders the node array into cache-line treelets. Children are addressed as a PAIR (lower child at
+// `info & 0x0fffffff`, upper child in the next slot), so a treelet is rooted at a pair: 16 slots = 128 bytes =
+// one L1/L2 line hold a pair, its four children and its eight grandchildren at fixed positions
+//   [0,1] pair | [2,3] kids of 0 | [4,5] kids of 1 | [6,7] [8,9] kids of 2,3 | [10,11] [12,13] kids of 4,5 | [14,15] unused
+// so three consecutive descent steps touch one line. Slots of children that do not exist stay INVALID holes.
+// The pairs below the third level start treelets of their own, laid out depth-first. Only positions change:
+// heap indices, leaf numbers and splits travel with their node.
+void relayout_treelets(KdTreeHost &t) {
+    const size_t n_old = t.nodes.size();
+    if (n_old < 2) return;
+    std::vector<KdNodeDev> nn;
+    std::vector<uint32_t> nh;
+    nn.reserve(n_old * 2);
+    nh.reserve(n_old * 2);
+    nn.push_back(t.nodes[0]);
+    nh.push_back(t.heap_index[0]);
+    for (int i = 1; i < 16; i++) { nn.push_back(KdNodeDev{0.0f, 0u}); nh.push_back(0xffffffffu); }   // root keeps a line of its own
+    struct Job { uint32_t old_pair; uint32_t parent_new; };   // pair to place; new index of the node that owns it
+    std::vector<Job> todo;
+    auto is_int = [](const KdNodeDev &n) { return (n.info >> 30) == 1u; };
+    if (is_int(t.nodes[0])) todo.push_back({t.nodes[0].info & 0x0fffffffu, 0u});
+    while (!todo.empty()) {
+        const Job j = todo.back();
+        todo.pop_back();
+        const uint32_t base = (uint32_t)nn.size();
+        nn.resize(base + 16, KdNodeDev{0.0f, 0u});
+        nh.resize(base + 16, 0xffffffffu);
+        nn[j.parent_new].info = (nn[j.parent_new].info & 0xf0000000u) | base;
+        // slot -> old node index for the three levels of this treelet
+        uint32_t old_of[14];
+        for (auto &o : old_of) o = 0xffffffffu;
+        old_of[0] = j.old_pair;
+        old_of[1] = j.old_pair + 1;
+        static const int kid_slot[6] = {2, 4, 6, 8, 10, 12};   // first kid slot of slots 0..5
+        for (int sl = 0; sl < 6; sl++) {
+            const uint32_t o = old_of[sl];
+            if (o == 0xffffffffu || !is_int(t.nodes[o])) continue;
+            const uint32_t c = t.nodes[o].info & 0x0fffffffu;
+            old_of[kid_slot[sl]] = c;
+            old_of[kid_slot[sl] + 1] = c + 1;
+        }
+        for (int sl = 0; sl < 14; sl++) {
+            const uint32_t o = old_of[sl];
+            if (o == 0xffffffffu) continue;
+            nn[base + sl] = t.nodes[o];
+            nh[base + sl] = t.heap_index[o];
+            if (sl < 6 && is_int(t.nodes[o])) nn[base + sl].info = (t.nodes[o].info & 0xf0000000u) | (base + (uint32_t)kid_slot[sl]);
+        }
+        // grandchildren that are internal own the pairs of the next treelets; push in reverse so that the
+        // lowest slot is laid out first
+        for (int sl = 13; sl >= 6; sl--) {
+            const uint32_t o = old_of[sl];
+            if (o != 0xffffffffu && is_int(t.nodes[o])) todo.push_back({t.nodes[o].info & 0x0fffffffu, base + (uint32_t)sl});
+        }
+    }
+    t.nodes.swap(nn);
+    t.heap_index.swap(nh);
 }
 
 void export_reference(const KdTreeHost &t, uint32_t *pairs) {
-    std::vector<std::pair<uint32_t, uint32_t>> v(t.nodes.size());
+    std::vector<std::pair<uint32_t, uint32_t>> v;
+    v.reserve(t.nodes.size());
     for (size_t i = 0; i < t.nodes.size(); i++) {
         uint32_t info = t.nodes[i].info, ty = info >> 30;
+        if (ty == 0) continue;   // hole of the treelet layout
         uint32_t meta = ty == 1 ? T_INTERNAL : (ty == 2 ? T_EMPTY : (T_LEAF | (info & 0x3fffffffu)));
-        v[i] = {t.heap_index[i], meta};
+        v.push_back({t.heap_index[i], meta});
     }
     std::sort(v.begin(), v.end());
     for (size_t i = 0; i < v.size(); i++) { pairs[2 * i] = v[i].first; pairs[2 * i + 1] = v[i].second; }

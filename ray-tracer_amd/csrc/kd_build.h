@@ -26,12 +26,13 @@ struct KdLeafDev {
 };
 
 struct KdTreeHost {
-    std::vector<KdNodeDev> nodes;     // nodes[0] = root
+    std::vector<KdNodeDev> nodes;     // nodes[0] = root; treelet layout, info == 0 marks an unused slot
     std::vector<uint32_t> heap_index; // reference heap index (2i+1 / 2i+2) of nodes[k]
     std::vector<KdLeafDev> leaves;    // reference leaf order
     double root_box[6];               // root.min, root.max as the builder computed them (f64)
     int depth = 0;                    // deepest node depth, root = 1
     int64_t n_internal = 0, n_leaf = 0, n_empty = 0;
+    int64_t n_nodes = 0;              // real nodes (nodes.size() also counts the unused slots)
 };
 
 // verts: n_verts*3 doubles; faces: n_faces*3 indices. infinity = the script's INFINITY constant.

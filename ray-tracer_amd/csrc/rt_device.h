@@ -34,12 +34,21 @@ struct LightDev {
 };
 
 // Triangle as the traversal wants it: vertex 0 and the two edges the reference's Moller-Trumbore
-// forms first (e1 = v1 - v0, e2 = v2 - v0 in float32, js/8-kd_tree.js:505-506), material index last.
+// forms first (e1 = v1 - v0, e2 = v2 - v0 in float32, js/8-kd_tree.js:505-506), then material and face index.
+// Two arrays hold these records: `tris` indexed by face, and `ltris` in leaf order - the (at most four) faces
+// of leaf 0, then those of leaf 1, ... - so that a leaf visit can name its triangles as a slot range without
+// reading a leaf record.
 struct TriDev {
     float v0[3], e1[3], e2[3];
     int32_t mat;
-    int32_t pad[2];
+    int32_t face;
+    int32_t pad;
 };
+
+// Device copy of a k-d node (see kd_build.h for internal nodes). Leaf info differs from the host form:
+// [31:30] = 3, [29:27] = number of faces (1..4), [26:0] = first slot in `ltris`.
+constexpr uint32_t LEAF_COUNT_SHIFT = 27;
+constexpr uint32_t LEAF_SLOT_MASK = (1u << LEAF_COUNT_SHIFT) - 1u;
 
 struct SceneDev {
     int32_t n_prims, n_mats, n_lights, n_faces;
@@ -53,7 +62,7 @@ struct SceneDev {
     const LightDev *lights;
     const TriDev *tris;
     const KdNodeDev *nodes;
-    const KdLeafDev *leaves;
+    const TriDev *ltris;
 };
 
 struct V3 {

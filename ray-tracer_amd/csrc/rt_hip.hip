@@ -22,7 +22,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-constexpr int N_STAGES = 5;   // k_gen_prims, k_kd_walk<closest>, k_shade_a, k_kd_walk<any>, k_shade_b
+constexpr int N_STAGES = 7;   // k_gen_prims, k_kd_walk<closest>, k_tri_test<closest>, k_shade_a, k_kd_walk<any>, k_tri_test<any>, k_shade_b
 
 // ------------------------------------------------------------------------------------------------
 struct Level {
@@ -48,6 +48,7 @@ struct rt_ctx {
     std::vector<rt_prim> prims_host;
     std::vector<double> verts;
     std::vector<uint32_t> faces, face_mat;
+    std::vector<TriDev> tris_host;
     KdTreeHost kd;
     bool kd_built = false, scene_dirty = true, mesh_dirty = true;
     SceneDev sh{};   // host mirror of the device scene header
@@ -58,14 +59,17 @@ struct rt_ctx {
     LightDev *d_lights = nullptr;
     TriDev *d_tris = nullptr;
     KdNodeDev *d_nodes = nullptr;
-    KdLeafDev *d_leaves = nullptr;
-    size_t cap_prims = 0, cap_mats = 0, cap_lights = 0, cap_tris = 0, cap_nodes = 0, cap_leaves = 0;
+    TriDev *d_ltris = nullptr;
+    bool tree_dirty = true;
+    size_t cap_prims = 0, cap_mats = 0, cap_lights = 0, cap_tris = 0, cap_nodes = 0, cap_ltris = 0;
     Level lv[MAX_LEVELS];
     LevelCounters *d_counts = nullptr;           // one block of counters per level
     uint32_t *d_kdq = nullptr;                   // closest-hit traversal queue (ray indices), reused by every level
     void *d_shq_mem = nullptr;                   // shadow traversal queue, reused by every level
     ShadowQ shq{};
     size_t cap_kdq = 0;
+    uint2 *d_recs = nullptr;                     // triangle records of the walk in flight, reused by every level
+    size_t cap_recs = 0;
     uint32_t cap_shq = 0;
     uint32_t n_rays[MAX_LEVELS]{};
     // frame
@@ -118,7 +122,8 @@ int ensure_level(rt_ctx *ctx, int l, uint32_t cap) {
     cap = std::max<uint32_t>((cap + 255u) & ~255u, 256u);
     HIPCK(hipMalloc(&L.mem, (size_t)cap * LEVEL_ARRAYS * sizeof(float)));
     L.cap = cap;
-    float *p = (float *)L.mem;
+    L.b.best = (unsigned long long *)L.mem;
+    float *p = (float *)L.mem + 2 * (size_t)cap;
     float **f[] = {&L.b.ox, &L.b.oy, &L.b.oz, &L.b.dx, &L.b.dy, &L.b.dz, &L.b.ht, &L.b.cr, &L.b.cg, &L.b.cb, &L.b.kr, &L.b.kt};
     for (auto q : f) { *q = p; p += cap; }
     L.b.hp = (uint32_t *)p; p += cap;
@@ -191,12 +196,46 @@ int upload_scene(rt_ctx *ctx) {
             TriDev &t = tris[f];
             for (int k = 0; k < 3; k++) { t.v0[k] = v[0][k]; t.e1[k] = v[1][k] - v[0][k]; t.e2[k] = v[2][k] - v[0][k]; }
             t.mat = find_mat((int)ctx->face_mat[2 * f], (int)ctx->face_mat[2 * f + 1]);
-            t.pad[0] = t.pad[1] = 0;
+            t.face = (int32_t)f;
+            t.pad = 0;
         }
         if (ensure(ctx, ctx->d_tris, ctx->cap_tris, nf)) return -1;
         if (nf) HIPCK(hipMemcpyAsync(ctx->d_tris, tris.data(), nf * sizeof(TriDev), hipMemcpyHostToDevice, ctx->stream));
         HIPCK(hipStreamSynchronize(ctx->stream));   // `tris` is a local
+        ctx->tris_host.swap(tris);
         ctx->mesh_dirty = false;
+        ctx->tree_dirty = true;
+    }
+    if (ctx->tree_dirty && ctx->kd_built) {
+        // device form of the tree: leaves name a slot range of the leaf-ordered triangle array
+        auto t0 = std::chrono::steady_clock::now();
+        const KdTreeHost &kd = ctx->kd;
+        std::vector<uint32_t> first(kd.leaves.size() + 1, 0);
+        for (size_t i = 0; i < kd.leaves.size(); i++) {
+            uint32_t c = 0;
+            for (int k = 0; k < 4; k++) c += kd.leaves[i].face[k] > -1;
+            first[i + 1] = first[i] + c;
+        }
+        if (first.back() > LEAF_SLOT_MASK) return fail(ctx, "k-d tree has too many leaf slots for the device layout");
+        std::vector<TriDev> ltris(first.back());
+        for (size_t i = 0; i < kd.leaves.size(); i++) {
+            uint32_t s0 = first[i];
+            for (int k = 0; k < 4; k++)
+                if (kd.leaves[i].face[k] > -1) ltris[s0++] = ctx->tris_host[(size_t)kd.leaves[i].face[k]];
+        }
+        std::vector<KdNodeDev> nodes(kd.nodes);
+        for (auto &n : nodes)
+            if ((n.info >> 30) == 3u) {
+                const uint32_t li = n.info & 0x3fffffffu;
+                n.info = (3u << 30) | ((first[li + 1] - first[li]) << LEAF_COUNT_SHIFT) | first[li];
+            }
+        if (ensure(ctx, ctx->d_nodes, ctx->cap_nodes, nodes.size())) return -1;
+        if (ensure(ctx, ctx->d_ltris, ctx->cap_ltris, ltris.size())) return -1;
+        HIPCK(hipMemcpyAsync(ctx->d_nodes, nodes.data(), nodes.size() * sizeof(KdNodeDev), hipMemcpyHostToDevice, ctx->stream));
+        if (!ltris.empty()) HIPCK(hipMemcpyAsync(ctx->d_ltris, ltris.data(), ltris.size() * sizeof(TriDev), hipMemcpyHostToDevice, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
+        ctx->st.kd_upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ctx->tree_dirty = false;
     }
 
     SceneDev &h = ctx->sh;
@@ -217,7 +256,7 @@ int upload_scene(rt_ctx *ctx) {
         }
     }
     h.prims = ctx->d_prims; h.mats = ctx->d_mats; h.lights = ctx->d_lights; h.tris = ctx->d_tris;
-    h.nodes = ctx->d_nodes; h.leaves = ctx->d_leaves;
+    h.nodes = ctx->d_nodes; h.ltris = ctx->d_ltris;
     HIPCK(hipMemcpyAsync(ctx->d_scene, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
     HIPCK(hipStreamSynchronize(ctx->stream));
     ctx->scene_dirty = false;
@@ -317,9 +356,9 @@ void rt_destroy(rt_ctx *ctx) {
     if (ctx->host_only) { delete ctx; return; }
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    void *ptrs[] = {ctx->d_scene, ctx->d_prims, ctx->d_mats, ctx->d_lights, ctx->d_tris, ctx->d_nodes, ctx->d_leaves,
+    void *ptrs[] = {ctx->d_scene, ctx->d_prims, ctx->d_mats, ctx->d_lights, ctx->d_tris, ctx->d_nodes, ctx->d_ltris,
                     ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_canvas, ctx->d_counts, ctx->d_kdq,
-                    ctx->d_shq_mem, ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt};
+                    ctx->d_recs, ctx->d_shq_mem, ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &l : ctx->lv)
@@ -412,16 +451,8 @@ int rt_build_kdtree(rt_ctx *ctx) {
         ctx->kd_built = true;
         return 0;
     }
-    HIPCK(hipSetDevice(ctx->cfg.device));
-    if (ensure(ctx, ctx->d_nodes, ctx->cap_nodes, ctx->kd.nodes.size())) return -1;
-    if (ensure(ctx, ctx->d_leaves, ctx->cap_leaves, ctx->kd.leaves.size())) return -1;
-    HIPCK(hipMemcpyAsync(ctx->d_nodes, ctx->kd.nodes.data(), ctx->kd.nodes.size() * sizeof(KdNodeDev), hipMemcpyHostToDevice, ctx->stream));
-    if (!ctx->kd.leaves.empty())
-        HIPCK(hipMemcpyAsync(ctx->d_leaves, ctx->kd.leaves.data(), ctx->kd.leaves.size() * sizeof(KdLeafDev), hipMemcpyHostToDevice, ctx->stream));
-    HIPCK(hipStreamSynchronize(ctx->stream));
-    auto t2 = std::chrono::steady_clock::now();
     ctx->st.kd_build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    ctx->st.kd_upload_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    ctx->tree_dirty = true;
     ctx->kd_built = true;
     ctx->scene_dirty = true;
     return 0;
@@ -430,7 +461,7 @@ int rt_build_kdtree(rt_ctx *ctx) {
 int rt_kdtree_counts(rt_ctx *ctx, int64_t *n_nodes, int64_t *n_leaves) {
     if (!ctx) return -1;
     if (!ctx->kd_built) return fail(ctx, "rt_kdtree_counts: no tree built");
-    if (n_nodes) *n_nodes = (int64_t)ctx->kd.nodes.size();
+    if (n_nodes) *n_nodes = ctx->kd.n_nodes;
     if (n_leaves) *n_leaves = (int64_t)ctx->kd.leaves.size();
     return 0;
 }
@@ -459,8 +490,9 @@ int rt_trace(rt_ctx *ctx) {
     if (ensure_level(ctx, 0, ctx->n0)) return -1;
     hipEvent_t ev_begin = ctx->ev_misc[0], ev_comp = ctx->ev_misc[1], ev_end = ctx->ev_misc[2];
     HIPCK(hipEventRecord(ev_begin, s));
-    // persistent traversal waves: one 64-lane workgroup each, 8.8 KB of LDS (short stack, rays, FIFO) -> 18 fit a CU
+    // persistent traversal waves: one 64-lane workgroup each (4 KB of LDS for the short stacks)
     const dim3 walk_grid((unsigned)ctx->n_cus * (unsigned)RT_WALK_WAVES_PER_CU);
+    const dim3 test_grid((unsigned)ctx->n_cus * 32u);   // grid-stride over the records
     int levels_run = 0;
     for (int l = 0; l < D; l++) {
         const uint32_t n = ctx->n_rays[l];
@@ -471,41 +503,58 @@ int rt_trace(rt_ctx *ctx) {
             if (ensure_level(ctx, l + 1, (uint32_t)want)) return -1;
         }
         if (ensure_queues(ctx, n, (uint32_t)sh.n_lights)) return -1;
-        LevelArgs A{};
-        A.S = ctx->sh;
-        A.cur = ctx->lv[l].b;
-        if (!last) { A.nxt = ctx->lv[l + 1].b; A.nxt_cap = ctx->lv[l + 1].cap; }
-        A.shq = ctx->shq;
-        A.shq_cap = ctx->cap_shq;
-        A.kdq = ctx->d_kdq;
-        A.cnt = ctx->d_counts + l;
-        A.n_rays = n;
-        A.hit_ids = ctx->d_hit;
-        A.g = ctx->g;
-        A.level = l;
-        A.last_level = last ? 1 : 0;
-        WalkArgs Wk{ctx->sh, ctx->lv[l].b, ctx->shq, ctx->d_kdq, ctx->d_counts + l, ctx->cap_shq};
-        const dim3 grid((n + BLOCK - 1) / BLOCK);
-        hipEvent_t *ev = ctx->ev[l];
-        HIPCK(hipEventRecord(ev[0], s));
-        hipLaunchKernelGGL(k_gen_prims, grid, dim3(BLOCK), 0, s, A);
-        HIPCK(hipEventRecord(ev[1], s));
-        if (walk) hipLaunchKernelGGL(k_kd_walk<false>, walk_grid, dim3(WAVE), 0, s, Wk);
-        HIPCK(hipEventRecord(ev[2], s));
-        hipLaunchKernelGGL(k_shade_a, grid, dim3(BLOCK), 0, s, A);
-        HIPCK(hipEventRecord(ev[3], s));
-        if (walk) hipLaunchKernelGGL(k_kd_walk<true>, walk_grid, dim3(WAVE), 0, s, Wk);
-        HIPCK(hipEventRecord(ev[4], s));
-        hipLaunchKernelGGL(k_shade_b, grid, dim3(BLOCK), 0, s, A);
-        HIPCK(hipGetLastError());
-        HIPCK(hipEventRecord(ev[5], s));
-        levels_run = l + 1;
-        if (!last) {
-            uint32_t cnt = 0;
-            HIPCK(hipMemcpyAsync(&cnt, &ctx->d_counts[l].next_count, sizeof cnt, hipMemcpyDeviceToHost, s));
+        if (walk && ctx->cap_recs == 0 && ensure(ctx, ctx->d_recs, ctx->cap_recs, std::max<size_t>((size_t)16 << 20, (size_t)n * 16))) return -1;
+        for (int attempt = 0;; attempt++) {
+            LevelArgs A{};
+            A.S = ctx->sh;
+            A.cur = ctx->lv[l].b;
+            if (!last) { A.nxt = ctx->lv[l + 1].b; A.nxt_cap = ctx->lv[l + 1].cap; }
+            A.shq = ctx->shq;
+            A.shq_cap = ctx->cap_shq;
+            A.kdq = ctx->d_kdq;
+            A.recs = ctx->d_recs;
+            A.rec_cap = (uint32_t)std::min<size_t>(ctx->cap_recs, 0x3fffff00u);
+            A.cnt = ctx->d_counts + l;
+            A.n_rays = n;
+            A.hit_ids = ctx->d_hit;
+            A.g = ctx->g;
+            A.level = l;
+            A.last_level = last ? 1 : 0;
+            WalkArgs Wk{ctx->sh, ctx->lv[l].b, ctx->shq, ctx->d_kdq, ctx->d_recs, ctx->d_counts + l, ctx->cap_shq, A.rec_cap};
+            const dim3 grid((n + BLOCK - 1) / BLOCK);
+            hipEvent_t *ev = ctx->ev[l];
+            HIPCK(hipEventRecord(ev[0], s));
+            hipLaunchKernelGGL(k_gen_prims, grid, dim3(BLOCK), 0, s, A);
+            HIPCK(hipEventRecord(ev[1], s));
+            if (walk) hipLaunchKernelGGL(k_kd_walk<false>, walk_grid, dim3(WAVE), 0, s, Wk);
+            HIPCK(hipEventRecord(ev[2], s));
+            if (walk) hipLaunchKernelGGL(k_tri_test<false>, test_grid, dim3(256), 0, s, Wk);
+            HIPCK(hipEventRecord(ev[3], s));
+            hipLaunchKernelGGL(k_shade_a, grid, dim3(BLOCK), 0, s, A);
+            HIPCK(hipEventRecord(ev[4], s));
+            if (walk) hipLaunchKernelGGL(k_kd_walk<true>, walk_grid, dim3(WAVE), 0, s, Wk);
+            HIPCK(hipEventRecord(ev[5], s));
+            if (walk) hipLaunchKernelGGL(k_tri_test<true>, test_grid, dim3(256), 0, s, Wk);
+            HIPCK(hipEventRecord(ev[6], s));
+            hipLaunchKernelGGL(k_shade_b, grid, dim3(BLOCK), 0, s, A);
+            HIPCK(hipGetLastError());
+            HIPCK(hipEventRecord(ev[7], s));
+            // one host round trip per level: the number of children (sizes the next level) and the record
+            // counts (a walk that ran out of record space wrote nothing past the capacity: repeat the level)
+            LevelCounters hc;
+            HIPCK(hipMemcpyAsync(&hc, ctx->d_counts + l, sizeof hc, hipMemcpyDeviceToHost, s));
             HIPCK(hipStreamSynchronize(s));
-            ctx->n_rays[l + 1] = std::min(cnt, ctx->lv[l + 1].cap);
+            const size_t need = std::max<size_t>(hc.rec_count[0], hc.rec_count[1]);
+            if (walk && need > A.rec_cap) {
+                if (attempt >= 3 || need > 0x3fffff00u) return fail(ctx, "rt_trace: triangle record buffer cannot hold one level");
+                if (ensure(ctx, ctx->d_recs, ctx->cap_recs, need + need / 4)) return -1;
+                HIPCK(hipMemsetAsync(ctx->d_counts + l, 0, sizeof(LevelCounters), s));
+                continue;
+            }
+            if (!last) ctx->n_rays[l + 1] = std::min(hc.next_count, ctx->lv[l + 1].cap);
+            break;
         }
+        levels_run = l + 1;
     }
     HIPCK(hipEventRecord(ev_comp, s));
     for (int l = levels_run - 2; l >= 0; l--) {
@@ -521,14 +570,6 @@ int rt_trace(rt_ctx *ctx) {
     HIPCK(hipMemcpyAsync(hc, ctx->d_counts, sizeof hc, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
 
-#if defined(RT_DBG_COUNT)
-    {
-        unsigned long long d[16] = {0};
-        for (int l = 0; l < levels_run; l++) for (int k = 0; k < 16; k++) d[k] += hc[l].dbg[k];
-        const char *names[8] = {"wave_iters", "lane_actions", "batches", "pairs", "refills", "restarts", "leaf_actions", "emit_iters"};
-        for (int k = 0; k < 8; k++) fprintf(stderr, "DBG %-12s closest %14llu  any %14llu\n", names[k], d[k], d[8 + k]);
-    }
-#endif
     rt_stats &st = ctx->st;
     const double keep_build = st.kd_build_ms, keep_upload = st.kd_upload_ms, keep_tone = st.tone_ms;
     memset(&st, 0, sizeof st);
@@ -549,6 +590,8 @@ int rt_trace(rt_ctx *ctx) {
         st.shadow_rays += (uint64_t)hc[l].shaded * (uint64_t)sh.n_lights;
         st.kd_closest_rays += hc[l].kdq_count;
         st.kd_shadow_rays += hc[l].shq_count;
+        st.tri_records[0] += hc[l].rec_count[0];
+        st.tri_records[1] += hc[l].rec_count[1];
         float ms = 0;
         for (int k = 0; k < N_STAGES; k++) {
             HIPCK(hipEventElapsedTime(&ms, ctx->ev[l][k], ctx->ev[l][k + 1]));

@@ -6,15 +6,22 @@
 // queues, and each level runs as a short pipeline of kernels whose lanes all do the same kind of work:
 //
 //   k_gen_prims    one lane per ray: (level 0: generate the primary ray) closest hit over the analytic
-//                  primitives; rays whose interval overlaps the k-d root box are appended to the
-//                  closest-hit traversal queue
-//   k_kd_walk<0>   persistent waves: closest-hit k-d traversal; a lane that finishes its ray pulls the
-//                  next one from the queue, so lanes stay busy although ray costs differ by 100x
-//   k_shade_a      one lane per ray: miss -> background; hit -> surface point, one shadow ray per light:
-//                  analytic any-hit test here, survivors that reach the k-d box go to the shadow queue
-//   k_kd_walk<1>   persistent waves: any-hit k-d traversal of the shadow queue, sets a bit per light
+//                  primitives; rays whose interval overlaps the k-d root box go to the walk queue
+//   k_kd_walk<0>   persistent waves walk the tree for the queued rays and only LIST the triangles of the
+//                  leaves they cross, as (ray, triangle slot) records in visit order
+//   k_tri_test<0>  one lane per record: Moller-Trumbore, 64-bit atomic min of (t, record index) per ray
+//   k_shade_a      one lane per ray: resolves the mesh hit, miss -> background, hit -> one shadow ray per
+//                  light: analytic any-hit test here, survivors that reach the k-d box go to the shadow queue
+//   k_kd_walk<1>   the same walk for the shadow queue
+//   k_tri_test<1>  one lane per record: any hit sets the light's shadow bit of the ray
 //   k_shade_b      one lane per ray: Phong terms with the shadow bits, spawns the children into the next
-//                  level's queue (wave-aggregated append: one atomic per wave, ranks from the ballot)
+//                  level's queue
+//
+// Walking and testing can be separated because the reference's closest-hit search never stops early: it
+// crosses every cell of the root interval and keeps the minimum t (js/8-kd_tree.js:862-962), so which
+// leaves are visited does not depend on any triangle test. For shadow rays the reference stops at the first
+// hit (js/8-kd_tree.js:685-687); walking on changes no result (any hit anywhere on the ray sets the same bit), and
+// testing in bulk afterwards measured faster than stopping lanes inside the walk (parked lanes idle the wave).
 //
 // Each parent remembers the queue slots of its two children; k_composite then folds colours level by
 // level in the reference's order (refracted child first, then reflected: js/8-kd_tree.js:1041-1054 walks
@@ -32,11 +39,12 @@ struct LevelBuf {
     uint32_t *hp;                        // analytic winner | last analytic hit << 16 (0xffff = none)
     int32_t *hf;                         // winning mesh face or -1
     uint32_t *shadow;                    // bit i: light i is occluded
+    unsigned long long *best;            // closest mesh hit: t bits << 32 | record index, ~0 = none
     float *cr, *cg, *cb;                 // local colour, later the folded colour
     float *kr, *kt;                      // kReflect / kRefract of this node
     int32_t *refl, *refr;                // queue slot of the child in the next level, -1 = none
 };
-constexpr int LEVEL_ARRAYS = 17;
+constexpr int LEVEL_ARRAYS = 19;        // 32-bit words per ray
 
 struct ShadowQ {                         // shadow rays that must walk the k-d tree
     float *ox, *oy, *oz, *dx, *dy, *dz;
@@ -58,8 +66,7 @@ struct LevelCounters {
     uint32_t shq_head, pad3[31];
     uint32_t next_count, pad4[31];
     uint32_t shaded, pad5[31];
-    unsigned long long dbg[16];   // RT_DBG_COUNT builds: [0] wave iterations [1] lane actions [2] batches [3] pairs
-                                  // [4] refills [5] restarts [6] leaf actions [7] emitting iterations  (+8 for any-hit)
+    uint32_t rec_count[2], pad6[30];      // triangle records written by the closest / shadow walk
 };
 
 constexpr int BLOCK = 1024;   // lanes per workgroup of the one-lane-per-ray kernels
@@ -69,8 +76,9 @@ struct LevelArgs {
     LevelBuf cur, nxt;
     ShadowQ shq;
     uint32_t *kdq;          // ray indices for the closest-hit traversal
+    const uint2 *recs;      // triangle records of the closest walk (k_shade_a resolves the winner)
     LevelCounters *cnt;
-    uint32_t n_rays, nxt_cap, shq_cap, pad;
+    uint32_t n_rays, nxt_cap, shq_cap, rec_cap;
     int32_t *hit_ids;       // level 0 only, full frame
     FrameGeom g;
     int32_t level, last_level;
@@ -176,41 +184,42 @@ __global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
         A.cur.ht[tid] = tMin;
         A.cur.hp[tid] = active ? (best | (last << 16)) : 0xfffeffffu;   // 0xfffe in the high half: lane outside the image
         A.cur.hf[tid] = face;
+        A.cur.best[tid] = ~0ull;
     }
     const uint32_t slot = block_reserve(to_kd ? 1u : 0u, &A.cnt->kdq_count, s_wave);
     if (to_kd) A.kdq[slot] = tid;
 }
 
-// ---- stages 2 and 4: persistent k-d traversal ------------------------------------------------------
-// Tree walk. The reference restarts from the "pushed" node for every cell the ray crosses (kd-pushdown,
-// js/8-kd_tree.js:862-962); here the far child and the interval end are kept on a per-lane stack in LDS
-// instead, which visits exactly the same leaves in the same order with the same comparisons: on a restart
-// every ancestor decision is re-derived from the same plane distance t, the same kdTMax and a kdTMin that
-// only grew, so it repeats, and the first node to decide differently is the one whose far child the stack
-// holds. A NaN plane distance (0/0) ends the walk after the current leaf in both forms (`kdTMax < maxDist`
-// is false for NaN). The plane distance uses a true IEEE division: a reciprocal multiply can differ in the
-// last bit and flip a `t >= kdTMax` decision.
-//
-// Closest hit keeps the minimum t over EVERY leaf crossed - no early exit, because a leaf keeps only its
-// first four faces and a later cell may list a triangle that an earlier, truncated cell dropped. That makes
-// the walk independent of the triangle tests, so the two are decoupled inside the wave:
-//   - every lane owns one ray and takes one tree action per iteration (a descent step, or at a leaf:
-//     queue its faces and pop the stack); lanes whose ray is finished are refilled from the global queue;
-//   - the faces go into a wave-local FIFO in LDS as (owner lane, face) pairs; whenever 64 pairs are waiting
-//     the whole wave runs one Moller-Trumbore test per lane on them, whatever lane owns the ray;
-//   - results come back through LDS: closest hit = 64-bit atomic min of (t bits, FIFO position) per owner,
-//     so equal distances resolve to the face met first, as the shader's strict `hitInfo.t < tMin` does
-//     (js/8-kd_tree.js:948-949); any hit = a flag per owner that stops that owner's walk.
-// Before a lane takes a new ray the FIFO is drained, so no pair ever outlives its ray.
+// ---- k-d walk ----------------------------------------------------------------------------------------
+// The reference restarts from the "pushed" node for every cell the ray crosses (kd-pushdown,
+// js/8-kd_tree.js:862-962). Here the far child and the interval end wait on a per-lane stack instead, which
+// visits exactly the same leaves in the same order with the same comparisons: on a restart every ancestor
+// decision is re-derived from the same plane distance t, the same kdTMax and a kdTMin that only grew, so it
+// repeats, and the first node to decide differently is the one whose far child the stack holds. A NaN plane
+// distance (0/0) ends the walk after the current leaf in both forms (`kdTMax < maxDist` is false for NaN).
+// The plane distance uses a true IEEE division: a reciprocal multiply can differ in the last bit and flip a
+// `t >= kdTMax` decision.
+// The stack is a ring of SHORT_STACK entries per lane in LDS; a push onto a full ring overwrites the oldest
+// entry. When the ring runs dry although the ray has not reached the end of the root interval, the walk
+// restarts at the root with kdTMin = the end of the cell just finished - what the reference does after EVERY
+// cell - so a restart re-derives exactly the dropped decisions.
+// Every lane owns one ray and takes one tree action per iteration (a descent step, or at a leaf: list its
+// triangles and pop); a lane whose ray is finished pulls the next one from the global queue.
 struct WalkArgs {
     SceneDev S;
     LevelBuf cur;
     ShadowQ shq;
     const uint32_t *kdq;
+    uint2 *recs;            // out: (ray reference, leaf face count << 27 | first slot in S.ltris)
     LevelCounters *cnt;
-    uint32_t shq_cap;
+    uint32_t shq_cap, rec_cap;
 };
 
+#if defined(RT_DBG_NO_EMIT)
+#define LEAF_EMIT_COND && false
+#else
+#define LEAF_EMIT_COND
+#endif
 #ifndef RT_REFILL_MIN_IDLE
 #define RT_REFILL_MIN_IDLE 16
 #endif
@@ -218,296 +227,188 @@ struct WalkArgs {
 #define RT_SHORT_STACK 8
 #endif
 #ifndef RT_WALK_WAVES_PER_CU
-#define RT_WALK_WAVES_PER_CU 16
+#define RT_WALK_WAVES_PER_CU 24
 #endif
-constexpr int REFILL_MIN_IDLE = RT_REFILL_MIN_IDLE;   // drain + refill once this many lanes of the wave have finished walking
-constexpr int REFILL_CHUNK = 256;     // rays a wave reserves from the global queue per atomic
-constexpr int FIFO_CAP = 512;         // >= 63 waiting + 64 lanes * 4 faces; power of two
-constexpr uint32_t OWNER_SHIFT = 26;  // pair = owner lane << 26 | face index
-// Far children wait on a short per-lane stack (ring of SHORT_STACK entries in LDS; a push onto a full
-// ring overwrites the oldest entry). When the ring runs dry although the ray has not reached the end of the
-// root interval, the walk restarts at the root with kdTMin = the end of the cell just finished - which is
-// what the reference does after EVERY cell, so a restart re-derives exactly the dropped decisions.
-constexpr int SHORT_STACK = RT_SHORT_STACK;   // power of two
-
-struct WalkLds {
-    uint2 stack[SHORT_STACK * WAVE];
-    float ro[3][WAVE], rd[3][WAVE];
-    unsigned long long best[WAVE];    // closest: (t bits << 32 | FIFO position), ~0 = none
-    uint32_t best_face[WAVE];
-    uint32_t hit_flag[WAVE];          // any-hit: owner's ray is occluded
-    uint32_t fifo[FIFO_CAP];
-    uint32_t fifo_tail;               // total pairs ever queued by this wave
-};
-
-// One batch of up to 64 (owner, face) pairs, split in two so that the triangle loads of a batch travel
-// together with the node loads of the walk: `batch_issue` reads the pairs and starts the loads,
-// `batch_finish` (one loop iteration later) runs the tests and posts the results.
-struct Batch {
-    bool valid;
-    uint32_t owner, face, pos;
-    float4 a, b;   // v0.xyz e1.x | e1.yz e2.xy
-    float c;       // e2.z
-};
-
-__device__ __forceinline__ void batch_issue(const SceneDev &S, WalkLds &L, uint32_t lane, uint32_t &q_head, uint32_t q_tail,
-                                            Batch &B) {
-    const uint32_t avail = q_tail - q_head;
-    const uint32_t n = avail < (uint32_t)WAVE ? avail : (uint32_t)WAVE;
-    B.valid = lane < n;
-    if (B.valid) {
-        const uint32_t e = L.fifo[(q_head + lane) & (FIFO_CAP - 1)];
-        B.owner = e >> OWNER_SHIFT;
-        B.face = e & ((1u << OWNER_SHIFT) - 1u);
-        B.pos = q_head + lane;
-        const float4 *t4 = reinterpret_cast<const float4 *>(S.tris + B.face);
-        B.a = t4[0];
-        B.b = t4[1];
-        B.c = reinterpret_cast<const float *>(t4 + 2)[0];
-    }
-    q_head += n;
-}
-
-template <bool ANY>
-__device__ __forceinline__ void batch_finish(const SceneDev &S, WalkLds &L, Batch &B) {
-    unsigned long long key = ~0ull;
-#if defined(RT_DBG_NO_TEST)
-    if (B.valid && B.a.x == 1.2345e33f) L.hit_flag[B.owner] = 2u;
-    B.valid = false;
-    return;
-#endif
-    if (B.valid && (!ANY || !L.hit_flag[B.owner])) {
-        const uint32_t o = B.owner;
-        const V3 ro = v3(L.ro[0][o], L.ro[1][o], L.ro[2][o]);
-        const V3 rd = v3(L.rd[0][o], L.rd[1][o], L.rd[2][o]);
-        float t;
-        if (hit_tri_regs(v3(B.a.x, B.a.y, B.a.z), v3(B.a.w, B.b.x, B.b.y), v3(B.b.z, B.b.w, B.c), S.tri_eps, ro, rd, t)) {
-            if (ANY) {
-                L.hit_flag[o] = 1u;
-            } else {
-                // t >= 0 here, so the float bits order like the values; -0 is folded onto +0
-                const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);
-                key = ((unsigned long long)tb << 32) | (unsigned long long)B.pos;
-                atomicMin(&L.best[o], key);
-            }
-        }
-    }
-    if (!ANY) {
-        __syncthreads();
-        if (key != ~0ull && L.best[B.owner] == key) L.best_face[B.owner] = B.face;   // keys are unique: one winner
-    }
-    __syncthreads();
-    B.valid = false;
-}
+constexpr int REFILL_MIN_IDLE = RT_REFILL_MIN_IDLE;   // refill once this many lanes of the wave have no ray
+constexpr int REFILL_CHUNK = 256;                    // rays a wave reserves from the global queue per atomic
+constexpr int REC_CHUNK = 4096;                      // records a wave reserves per atomic
+constexpr int SHORT_STACK = RT_SHORT_STACK;          // power of two
+constexpr uint32_t REC_FILLER = 0u;   // a record's second word is count << 27 | first slot; count 0 = filler
 
 template <bool ANY>
 __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
-    __shared__ WalkLds L;
+    __shared__ uint2 s_stack[SHORT_STACK * WAVE];
     const SceneDev &S = A.S;
     const KdNodeDev *__restrict__ nodes = S.nodes;
     const uint32_t lane = threadIdx.x;
-    uint2 *stack = L.stack + lane;
+    uint2 *stack = s_stack + lane;
     const uint32_t total = ANY ? min(A.cnt->shq_count, A.shq_cap) : A.cnt->kdq_count;
     uint32_t *head = ANY ? &A.cnt->shq_head : &A.cnt->kdq_head;
+    uint32_t *rec_count = &A.cnt->rec_count[ANY ? 1 : 0];
     const KdNodeDev root = nodes[0];
+    const unsigned long long below = (1ull << lane) - 1ull;
 
-    enum { IDLE = 0, WALK = 1, WAIT = 2, FETCH = 3 };
-    int state = IDLE;
+    // wave-uniform values are passed through readfirstlane so that they live in scalar registers and
+    // conditions on them compile to scalar branches instead of lane-mask arithmetic
+#define UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+    bool walking = false;
+    uint32_t more = 1u;                      // wave-uniform: the global queue may still hold rays
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
-    float tmin = 0.0f, tmax = 0.0f, maxDist = 0.0f, prim_t = 0.0f;
-    uint32_t id = 0, info = 0;
+    float tmin = 0.0f, tmax = 0.0f, maxDist = 0.0f;
+    uint32_t ref = 0, info = 0;
     float split = 0.0f;
     uint32_t sp_top = 0, sp_cnt = 0;
-    uint32_t q_head = 0, q_tail = 0;          // wave-uniform FIFO positions (grow without wrapping back)
-    uint32_t chunk_pos = 0, chunk_end = 0;    // wave-uniform: rays reserved from the global queue
-    bool more = true;
-    bool leaf_pending = false;                // lf holds a leaf loaded in the previous iteration
-    KdLeafDev lf = {{-1, -1, -1, -1}};
-    Batch B;
-    B.valid = false;
-    B.owner = B.face = B.pos = 0;
-    B.a = B.b = make_float4(0, 0, 0, 0);
-    B.c = 0.0f;
+    uint32_t chunk_pos = 0, chunk_end = 0;   // wave-uniform: rays reserved from the global queue
+    uint32_t rec_pos = 0, rec_end = 0;       // wave-uniform: record slots reserved in A.recs
 
-#if defined(RT_DBG_COUNT)
-    unsigned long long c_iter = 0, c_act = 0, c_batch = 0, c_pairs = 0, c_refill = 0, c_restart = 0, c_leaf = 0, c_emit_it = 0;
-#define DBG(x) x
-#else
-#define DBG(x)
-#endif
     for (;;) {
-        DBG(c_iter++;)
-        // ---- 1. finish the batch whose triangle loads were started one iteration ago
-        if (__any(B.valid)) batch_finish<ANY>(S, L, B);
-
-        // ---- 2. queue the faces of leaves reached in the previous iteration; the k-th faces of all lanes
-        //         form one group, groups in slot order, so one owner's pairs keep the leaf's face order
-        {
-            uint32_t n_emit = 0;
-            if (leaf_pending) n_emit = (lf.face[0] > -1) + (lf.face[1] > -1) + (lf.face[2] > -1) + (lf.face[3] > -1);
-            leaf_pending = false;
-            const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const unsigned long long m = __ballot(n_emit > (uint32_t)k);
-                if (!m) break;
-                DBG(if (k == 0) c_emit_it++;)
-                if (n_emit > (uint32_t)k)
-                    L.fifo[(q_tail + (uint32_t)__popcll(m & below)) & (FIFO_CAP - 1)] = (lane << OWNER_SHIFT) | (uint32_t)lf.face[k];
-                q_tail += (uint32_t)__popcll(m);
-            }
-        }
-
-        // ---- 3. while the global queue has rays: refill as soon as enough lanes are free; afterwards finished
-        //         lanes just wait for the last walkers of the wave
-        const int n_not_walking = __popcll(__ballot(state != WALK));
-        if (more ? (n_not_walking >= REFILL_MIN_IDLE) : (n_not_walking == WAVE)) {
-            __syncthreads();
-            DBG(c_refill++;)
-            while (q_head != q_tail) {   // drain: no pair may outlive its ray
-                DBG(c_batch++; c_pairs += (q_tail - q_head < 64u ? q_tail - q_head : 64u);)
-                batch_issue(S, L, lane, q_head, q_tail, B);
-                batch_finish<ANY>(S, L, B);
-            }
-            if (state == WAIT) {
-                if (ANY) {
-                    if (L.hit_flag[lane]) atomicOr(&A.cur.shadow[id >> 5], 1u << (id & 31u));
-                } else {
-                    const unsigned long long key = L.best[lane];
-                    if (key != ~0ull && __uint_as_float((uint32_t)(key >> 32)) < prim_t) {
-                        const int32_t f = (int32_t)L.best_face[lane];
-                        float t = 0.0f;
-                        hit_tri(S.tris[f], S.tri_eps, v3(ox, oy, oz), v3(dx, dy, dz), t);   // exact t of the winner
-                        A.cur.ht[id] = t;
-                        A.cur.hf[id] = f;
-                    }
-                }
-                state = IDLE;
-            }
-            if (more) {
-                const unsigned long long idle = __ballot(state == IDLE);
-                const uint32_t n_idle = (uint32_t)__popcll(idle);
-                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        // ---- refill: while the global queue has rays, as soon as enough lanes are free
+        const unsigned long long idle = __ballot(!walking);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle >= (uint32_t)REFILL_MIN_IDLE) {
+            if (!more) {
+                if (n_idle == (uint32_t)WAVE) break;
+            } else {
+                const uint32_t rank = (uint32_t)__popcll(idle & below);
                 const uint32_t left = chunk_end - chunk_pos;
-                uint32_t q = 0xffffffffu;
+                uint32_t q;
                 if (left < n_idle) {
                     // the rays left in the old chunk are taken first, the rest comes from a new chunk
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(head, (uint32_t)REFILL_CHUNK);
-                    base = __shfl(base, 0);
+                    base = UNIFORM(base);
                     q = rank < left ? chunk_pos + rank : base + (rank - left);
                     chunk_pos = base + (n_idle - left);
                     chunk_end = base + (uint32_t)REFILL_CHUNK;
-                    if (base >= total) { more = false; chunk_pos = chunk_end = 0; }
+                    if (base >= total) { more = 0u; chunk_pos = chunk_end = 0u; }
                 } else {
                     q = chunk_pos + rank;
                     chunk_pos += n_idle;
                 }
-                if (state == IDLE && q < total) {
+                if (!walking && q < total) {
                     if (ANY) {
+                        ref = q;
                         ox = A.shq.ox[q]; oy = A.shq.oy[q]; oz = A.shq.oz[q];
                         dx = A.shq.dx[q]; dy = A.shq.dy[q]; dz = A.shq.dz[q];
-                        id = A.shq.id[q];
                     } else {
-                        id = A.kdq[q];
-                        ox = A.cur.ox[id]; oy = A.cur.oy[id]; oz = A.cur.oz[id];
-                        dx = A.cur.dx[id]; dy = A.cur.dy[id]; dz = A.cur.dz[id];
-                        prim_t = A.cur.ht[id];
+                        ref = A.kdq[q];
+                        ox = A.cur.ox[ref]; oy = A.cur.oy[ref]; oz = A.cur.oz[ref];
+                        dx = A.cur.dx[ref]; dy = A.cur.dy[ref]; dz = A.cur.dz[ref];
                     }
                     ray_box(S, v3(ox, oy, oz), v3(dx, dy, dz), tmin, maxDist);
                     tmax = maxDist;
                     sp_top = sp_cnt = 0;
                     info = root.info;
                     split = root.split;
-                    L.ro[0][lane] = ox; L.ro[1][lane] = oy; L.ro[2][lane] = oz;
-                    L.rd[0][lane] = dx; L.rd[1][lane] = dy; L.rd[2][lane] = dz;
-                    L.best[lane] = ~0ull;
-                    L.hit_flag[lane] = 0u;
-                    // queued rays always satisfy tmin < maxDist; the test keeps the walk self-contained
-                    state = (tmin < maxDist) ? WALK : WAIT;
+                    walking = tmin < maxDist;   // always true for queued rays; keeps the walk self-contained
                 }
-                __syncthreads();
-            }
-            if (!__any(state != IDLE)) {
-                if (!more) break;
-                continue;
+                if (!__any(walking)) continue;
             }
         }
-        DBG(c_act += (unsigned long long)__popcll(__ballot(state == WALK));)
 
-        // ---- 4. start the loads of the next batch
-#if defined(RT_DBG_DROP_FIFO)
-        q_head = q_tail;
-#endif
-        if (q_tail - q_head >= (uint32_t)WAVE) {
-            __syncthreads();
-            DBG(c_batch++; c_pairs += 64;)
-            batch_issue(S, L, lane, q_head, q_tail, B);
+        // ---- one tree action per walking lane, written as straight-line predicated code: nested branches cost
+        //      a handful of scalar exec-mask instructions each, and the scalar unit is shared by the whole CU
+        const uint32_t type = info >> 30;
+        const bool is_int = walking && type == 1u;
+        const bool at_leaf = walking && type != 1u;
+        // internal node: classify the children and pick the side(s) the ray interval touches
+        const uint32_t a = (info >> 28) & 3u;
+        const float o = a == 0u ? ox : (a == 1u ? oy : oz), d = a == 0u ? dx : (a == 1u ? dy : dz);
+        const float t = (split - o) / d;
+        const uint32_t child = info & 0x0fffffffu;
+        const uint32_t neg = d <= 0.0f ? 1u : 0u;
+        const uint32_t nearc = child + neg, farc = child + 1u - neg;
+        const bool ge = t >= tmax, le = t <= tmin;
+        const bool both = is_int && !ge && !le;
+        uint32_t next = (le && !ge) ? farc : nearc;
+        if (both) stack[(sp_top & (SHORT_STACK - 1)) * WAVE] = make_uint2(farc, __float_as_uint(tmax));
+        // leaf (or empty leaf): list it, then go on with the next cell of the ray
+        const uint32_t leaf_info = (at_leaf && type == 3u LEAF_EMIT_COND) ? (info & 0x3fffffffu) : 0u;
+        const bool cont = at_leaf && tmax < maxDist;   // false on the last cell and on a NaN interval
+        const bool pop = cont && sp_cnt != 0u;
+        uint2 e = make_uint2(0u, __float_as_uint(maxDist));   // ring ran dry: restart at the root up to maxDist
+        if (pop) e = stack[((sp_top - 1u) & (SHORT_STACK - 1)) * WAVE];
+        sp_top = sp_top + (both ? 1u : 0u) - (pop ? 1u : 0u);
+        sp_cnt = both ? (sp_cnt < (uint32_t)SHORT_STACK ? sp_cnt + 1u : sp_cnt) : (pop ? sp_cnt - 1u : sp_cnt);
+        tmin = cont ? tmax : tmin;
+        tmax = cont ? __uint_as_float(e.y) : (both ? t : tmax);
+        next = cont ? e.x : next;
+        walking = walking && (is_int || cont);
+        if (walking) {
+            const KdNodeDev n = nodes[next];
+            info = n.info;
+            split = n.split;
         }
 
-        // ---- 5. one tree action per walking lane; its loads are consumed in the next iteration
-        if (state == WALK) {
-            if (ANY && L.hit_flag[lane]) {
-                state = WAIT;
-            } else if ((info >> 30) == 1u) {
-                const int a = (int)((info >> 28) & 3u);
-                const float o = a == 0 ? ox : (a == 1 ? oy : oz), d = a == 0 ? dx : (a == 1 ? dy : dz);
-                const float t = (split - o) / d;
-                uint32_t nearc = info & 0x0fffffffu, farc = nearc + 1;
-                if (d <= 0.0f) { const uint32_t tmp = nearc; nearc = farc; farc = tmp; }
-                uint32_t next;
-                if (t >= tmax) {
-                    next = nearc;
-                } else if (t <= tmin) {
-                    next = farc;
-                } else {
-                    stack[(sp_top & (SHORT_STACK - 1)) * WAVE] = make_uint2(farc, __float_as_uint(tmax));
-                    sp_top++;
-                    sp_cnt = sp_cnt < (uint32_t)SHORT_STACK ? sp_cnt + 1 : sp_cnt;
-                    next = nearc;
-                    tmax = t;
+        // ---- list the leaves just visited: one record (ray, leaf's slot range) per non-empty leaf; records of
+        //      one ray only ever move forward in the buffer, so the buffer order is the visit order
+        {
+            const unsigned long long m = __ballot(leaf_info != 0u);
+            if (m) {
+                const uint32_t tot = (uint32_t)__popcll(m);
+                if (rec_end - rec_pos < tot) {
+                    for (uint32_t p = rec_pos + lane; p < rec_end; p += WAVE) A.recs[p] = make_uint2(0u, REC_FILLER);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(rec_count, (uint32_t)REC_CHUNK);
+                    base = UNIFORM(base);
+                    rec_pos = base;
+                    // past the capacity nothing is written; the host sees rec_count > capacity and repeats
+                    // the level with a larger buffer
+                    rec_end = (base + (uint32_t)REC_CHUNK <= A.rec_cap) ? base + (uint32_t)REC_CHUNK : base;
                 }
-                const KdNodeDev n = nodes[next];
-                info = n.info;
-                split = n.split;
-            } else {
-                DBG(atomicAdd(&A.cnt->dbg[(ANY ? 8 : 0) + 6], 1ull);)
-#if !defined(RT_DBG_NO_EMIT)
-                if ((info >> 30) == 3u) {
-                    lf = S.leaves[info & 0x3fffffffu];
-                    leaf_pending = true;
-                }
-#endif
-                if (!(tmax < maxDist)) {   // last cell of the ray (or NaN interval)
-                    state = WAIT;
-                } else if (sp_cnt) {
-                    sp_top--;
-                    sp_cnt--;
-                    const uint2 e = stack[(sp_top & (SHORT_STACK - 1)) * WAVE];
-                    tmin = tmax;
-                    tmax = __uint_as_float(e.y);
-                    const KdNodeDev n = nodes[e.x];
-                    info = n.info;
-                    split = n.split;
-                } else {                   // ring ran dry: restart from the root for the rest of the ray
-                    DBG(atomicAdd(&A.cnt->dbg[(ANY ? 8 : 0) + 5], 1ull);)
-                    tmin = tmax;
-                    tmax = maxDist;
-                    info = root.info;
-                    split = root.split;
+                if (rec_end - rec_pos >= tot) {
+                    if (leaf_info) A.recs[rec_pos + (uint32_t)__popcll(m & below)] = make_uint2(ref, leaf_info);
+                    rec_pos += tot;
                 }
             }
         }
     }
-#if defined(RT_DBG_COUNT)
-    if (lane == 0) {
-        unsigned long long *d = A.cnt->dbg + (ANY ? 8 : 0);
-        atomicAdd(d + 0, c_iter); atomicAdd(d + 1, c_act); atomicAdd(d + 2, c_batch); atomicAdd(d + 3, c_pairs);
-        atomicAdd(d + 4, c_refill); atomicAdd(d + 7, c_emit_it);
+    for (uint32_t p = rec_pos + lane; p < rec_end; p += WAVE) A.recs[p] = make_uint2(0u, REC_FILLER);
+#undef UNIFORM
+}
+
+// ---- triangle tests over the records of a walk -------------------------------------------------------------
+// Closest hit: the shader tests a leaf's faces in order and keeps a hit only if `hitInfo.t < tMin`
+// (js/8-kd_tree.js:948-949), i.e. among equal distances the face met FIRST wins. Records of one ray sit in
+// the buffer in visit order, so the 64-bit key (t bits, record index * 4 + face slot) ordered by an atomic min
+// reproduces that. (Record indices stay below 2^30: the buffer capacity is capped accordingly.)
+template <bool ANY>
+__global__ __launch_bounds__(256) void k_tri_test(WalkArgs A) {
+    const SceneDev &S = A.S;
+    const uint32_t n_rec = min(A.cnt->rec_count[ANY ? 1 : 0], A.rec_cap);
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
+        const uint2 rec = A.recs[r];
+        const uint32_t count = rec.y >> LEAF_COUNT_SHIFT, first = rec.y & LEAF_SLOT_MASK;
+        if (count == 0u) continue;
+        V3 ro, rd;
+        uint32_t id = 0;
+        if (ANY) {
+            const uint32_t q = rec.x;
+            id = A.shq.id[q];
+            if (A.cur.shadow[id >> 5] & (1u << (id & 31u))) continue;   // already known to be occluded
+            ro = v3(A.shq.ox[q], A.shq.oy[q], A.shq.oz[q]);
+            rd = v3(A.shq.dx[q], A.shq.dy[q], A.shq.dz[q]);
+        } else {
+            const uint32_t i = rec.x;
+            ro = v3(A.cur.ox[i], A.cur.oy[i], A.cur.oz[i]);
+            rd = v3(A.cur.dx[i], A.cur.dy[i], A.cur.dz[i]);
+        }
+        unsigned long long key = ~0ull;
+        for (uint32_t k = 0; k < count; k++) {
+            float t;
+            if (hit_tri(S.ltris[first + k], S.tri_eps, ro, rd, t)) {
+                // t >= 0 here, so the float bits order like the values; -0 is folded onto +0
+                const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);
+                const unsigned long long kk = ((unsigned long long)tb << 32) | (unsigned long long)(r * 4u + k);
+                key = kk < key ? kk : key;
+                if (ANY) break;
+            }
+        }
+        if (key != ~0ull) {
+            if (ANY) atomicOr(&A.cur.shadow[id >> 5], 1u << (id & 31u));
+            else atomicMin(&A.cur.best[rec.x], key);
+        }
     }
-    (void)c_restart; (void)c_leaf;
-#endif
-#undef DBG
 }
 
 // ---- surface reconstruction ------------------------------------------------------------------------
@@ -562,8 +463,22 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
     const uint32_t hp = A.cur.hp[i];
     const bool active = in_range && (hp >> 16) != 0xfffeu;
     V3 ro = v3(A.cur.ox[i], A.cur.oy[i], A.cur.oz[i]), rd = v3(A.cur.dx[i], A.cur.dy[i], A.cur.dz[i]);
+    // mesh hit of the closest-hit walk: it replaces the analytic hit only if strictly nearer (js/8-kd_tree.js:948-949)
+    float ht = A.cur.ht[i];
+    int32_t hf = A.cur.hf[i];
+    if (active) {
+        const unsigned long long key = A.cur.best[i];
+        if (key != ~0ull && __uint_as_float((uint32_t)(key >> 32)) < ht) {
+            const uint32_t kr = (uint32_t)key;
+            const TriDev &T = S.ltris[(A.recs[kr >> 2].y & LEAF_SLOT_MASK) + (kr & 3u)];
+            hit_tri(T, S.tri_eps, ro, rd, ht);   // the winner's exact t (the key folds -0 onto +0)
+            hf = T.face;
+            A.cur.ht[i] = ht;
+            A.cur.hf[i] = hf;
+        }
+    }
     Surface sf;
-    const bool hit = active && make_surface(S, ro, rd, A.cur.ht[i], hp, A.cur.hf[i], sf);
+    const bool hit = active && make_surface(S, ro, rd, ht, hp, hf, sf);
     if (in_range && !hit) {
         V3 c = active ? ld3(S.bg) : v3(0, 0, 0);
         A.cur.cr[tid] = c.x; A.cur.cg[tid] = c.y; A.cur.cb[tid] = c.z;
