@@ -122,9 +122,10 @@ int ensure_level(rt_ctx *ctx, int l, uint32_t cap) {
     cap = std::max<uint32_t>((cap + 255u) & ~255u, 256u);
     HIPCK(hipMalloc(&L.mem, (size_t)cap * LEVEL_ARRAYS * sizeof(float)));
     L.cap = cap;
-    L.b.best = (unsigned long long *)L.mem;
-    float *p = (float *)L.mem + 2 * (size_t)cap;
-    float **f[] = {&L.b.ox, &L.b.oy, &L.b.oz, &L.b.dx, &L.b.dy, &L.b.dz, &L.b.ht, &L.b.cr, &L.b.cg, &L.b.cb, &L.b.kr, &L.b.kt};
+    L.b.ray = (float4 *)L.mem;   // widest alignment first; cap is a multiple of 256
+    L.b.best = (unsigned long long *)((float *)L.mem + 8 * (size_t)cap);
+    float *p = (float *)L.mem + 10 * (size_t)cap;
+    float **f[] = {&L.b.ht, &L.b.cr, &L.b.cg, &L.b.cb, &L.b.kr, &L.b.kt};
     for (auto q : f) { *q = p; p += cap; }
     L.b.hp = (uint32_t *)p; p += cap;
     L.b.hf = (int32_t *)p; p += cap;
@@ -145,10 +146,7 @@ int ensure_queues(rt_ctx *ctx, uint32_t n_rays, uint32_t n_lights) {
     uint32_t cap = std::max<uint32_t>(((uint32_t)want + 255u) & ~255u, 256u);
     HIPCK(hipMalloc(&ctx->d_shq_mem, (size_t)cap * SHADOWQ_ARRAYS * sizeof(float)));
     ctx->cap_shq = cap;
-    float *p = (float *)ctx->d_shq_mem;
-    float **f[] = {&ctx->shq.ox, &ctx->shq.oy, &ctx->shq.oz, &ctx->shq.dx, &ctx->shq.dy, &ctx->shq.dz};
-    for (auto q : f) { *q = p; p += cap; }
-    ctx->shq.id = (uint32_t *)p;
+    ctx->shq.ray = (float4 *)ctx->d_shq_mem;
     return 0;
 }
 
@@ -592,6 +590,10 @@ int rt_trace(rt_ctx *ctx) {
         st.kd_shadow_rays += hc[l].shq_count;
         st.tri_records[0] += hc[l].rec_count[0];
         st.tri_records[1] += hc[l].rec_count[1];
+#ifdef RT_WALK_STATS
+        fprintf(stderr, "walk stats level %d: closest iters %llu visits %llu | shadow iters %llu visits %llu\n", l, hc[l].walk_iters[0],
+                hc[l].walk_visits[0], hc[l].walk_iters[1], hc[l].walk_visits[1]);
+#endif
         float ms = 0;
         for (int k = 0; k < N_STAGES; k++) {
             HIPCK(hipEventElapsedTime(&ms, ctx->ev[l][k], ctx->ev[l][k + 1]));

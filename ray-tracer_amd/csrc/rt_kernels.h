@@ -34,7 +34,8 @@ namespace rt {
 
 // one ray-tree level, structure of arrays, `cap` entries each
 struct LevelBuf {
-    float *ox, *oy, *oz, *dx, *dy, *dz;  // ray
+    float4 *ray;                         // ray[2i] = origin, ray[2i+1] = direction (w unused): one 32-byte record,
+                                         // so that the gathers of the walk and of the triangle tests touch one line
     float *ht;                           // closest hit distance (INFINITY constant = miss so far)
     uint32_t *hp;                        // analytic winner | last analytic hit << 16 (0xffff = none)
     int32_t *hf;                         // winning mesh face or -1
@@ -44,13 +45,12 @@ struct LevelBuf {
     float *kr, *kt;                      // kReflect / kRefract of this node
     int32_t *refl, *refr;                // queue slot of the child in the next level, -1 = none
 };
-constexpr int LEVEL_ARRAYS = 19;        // 32-bit words per ray
+constexpr int LEVEL_ARRAYS = 21;        // 32-bit words per ray
 
 struct ShadowQ {                         // shadow rays that must walk the k-d tree
-    float *ox, *oy, *oz, *dx, *dy, *dz;
-    uint32_t *id;                        // ray index << 5 | light
+    float4 *ray;                         // ray[2q] = origin, w = bits of (ray index << 5 | light); ray[2q+1] = direction
 };
-constexpr int SHADOWQ_ARRAYS = 7;
+constexpr int SHADOWQ_ARRAYS = 8;
 constexpr int MAX_LIGHTS = 32;
 
 struct FrameGeom {
@@ -67,6 +67,7 @@ struct LevelCounters {
     uint32_t next_count, pad4[31];
     uint32_t shaded, pad5[31];
     uint32_t rec_count[2], pad6[30];      // triangle records written by the closest / shadow walk
+    unsigned long long walk_iters[2], walk_visits[2], pad7[12];   // RT_WALK_STATS builds only: wave iterations, lane node visits
 };
 
 constexpr int BLOCK = 1024;   // lanes per workgroup of the one-lane-per-ray kernels
@@ -99,6 +100,16 @@ __device__ __forceinline__ V3 mix3(V3 a, V3 b, float t) {
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ void load_ray(const float4 *ray, uint32_t i, V3 &ro, V3 &rd) {
+    const float4 o = ray[2 * (size_t)i], d = ray[2 * (size_t)i + 1];
+    ro = v3(o.x, o.y, o.z);
+    rd = v3(d.x, d.y, d.z);
+}
+__device__ __forceinline__ void store_ray(float4 *ray, uint32_t i, V3 ro, V3 rd, uint32_t tag = 0u) {
+    ray[2 * (size_t)i] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(tag));
+    ray[2 * (size_t)i + 1] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+}
 
 // Reserves `c` consecutive slots per lane in a global queue with ONE atomic per workgroup (an atomic per
 // wave on a single address serialises at roughly 10 ns each and was the floor of these kernels):
@@ -147,14 +158,10 @@ __global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
         float fx = ((float)px + 0.5f) / (float)A.g.W, fy = ((float)py + 0.5f) / (float)A.g.H;
         V3 dir = mix3(mix3(ld3(S.r00), ld3(S.r01), fy), mix3(ld3(S.r10), ld3(S.r11), fy), fx);
         rd = normalize(dir);
-        if (tid < A.n_rays) {
-            A.cur.ox[tid] = ro.x; A.cur.oy[tid] = ro.y; A.cur.oz[tid] = ro.z;
-            A.cur.dx[tid] = rd.x; A.cur.dy[tid] = rd.y; A.cur.dz[tid] = rd.z;
-        }
+        if (tid < A.n_rays) store_ray(A.cur.ray, tid, ro, rd);
     } else {
         uint32_t i = active ? tid : 0;
-        ro = v3(A.cur.ox[i], A.cur.oy[i], A.cur.oz[i]);
-        rd = v3(A.cur.dx[i], A.cur.dy[i], A.cur.dz[i]);
+        load_ray(A.cur.ray, i, ro, rd);
     }
     float tMin = S.inf;
     uint32_t best = 0xffffu, last = 0xffffu;
@@ -231,7 +238,10 @@ struct WalkArgs {
 #endif
 constexpr int REFILL_MIN_IDLE = RT_REFILL_MIN_IDLE;   // refill once this many lanes of the wave have no ray
 constexpr int REFILL_CHUNK = 256;                    // rays a wave reserves from the global queue per atomic
-constexpr int REC_CHUNK = 4096;                      // records a wave reserves per atomic
+#ifndef RT_REC_CHUNK
+#define RT_REC_CHUNK 512
+#endif
+constexpr int REC_CHUNK = RT_REC_CHUNK;                      // records a wave reserves per atomic
 constexpr int SHORT_STACK = RT_SHORT_STACK;          // power of two
 constexpr uint32_t REC_FILLER = 0u;   // a record's second word is count << 27 | first slot; count 0 = filler
 
@@ -260,6 +270,9 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
     uint32_t sp_top = 0, sp_cnt = 0;
     uint32_t chunk_pos = 0, chunk_end = 0;   // wave-uniform: rays reserved from the global queue
     uint32_t rec_pos = 0, rec_end = 0;       // wave-uniform: record slots reserved in A.recs
+#ifdef RT_WALK_STATS
+    unsigned long long st_iters = 0, st_visits = 0;
+#endif
 
     for (;;) {
         // ---- refill: while the global queue has rays, as soon as enough lanes are free
@@ -286,15 +299,11 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
                     chunk_pos += n_idle;
                 }
                 if (!walking && q < total) {
-                    if (ANY) {
-                        ref = q;
-                        ox = A.shq.ox[q]; oy = A.shq.oy[q]; oz = A.shq.oz[q];
-                        dx = A.shq.dx[q]; dy = A.shq.dy[q]; dz = A.shq.dz[q];
-                    } else {
-                        ref = A.kdq[q];
-                        ox = A.cur.ox[ref]; oy = A.cur.oy[ref]; oz = A.cur.oz[ref];
-                        dx = A.cur.dx[ref]; dy = A.cur.dy[ref]; dz = A.cur.dz[ref];
-                    }
+                    ref = ANY ? q : A.kdq[q];
+                    const float4 *rp = (ANY ? A.shq.ray : A.cur.ray) + 2 * (size_t)ref;
+                    const float4 fo = rp[0], fd = rp[1];
+                    ox = fo.x; oy = fo.y; oz = fo.z;
+                    dx = fd.x; dy = fd.y; dz = fd.z;
                     ray_box(S, v3(ox, oy, oz), v3(dx, dy, dz), tmin, maxDist);
                     tmax = maxDist;
                     sp_top = sp_cnt = 0;
@@ -308,6 +317,10 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
 
         // ---- one tree action per walking lane, written as straight-line predicated code: nested branches cost
         //      a handful of scalar exec-mask instructions each, and the scalar unit is shared by the whole CU
+#ifdef RT_WALK_STATS
+        st_iters++;
+        st_visits += (unsigned long long)__popcll(__ballot(walking));
+#endif
         const uint32_t type = info >> 30;
         const bool is_int = walking && type == 1u;
         const bool at_leaf = walking && type != 1u;
@@ -364,6 +377,12 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
         }
     }
     for (uint32_t p = rec_pos + lane; p < rec_end; p += WAVE) A.recs[p] = make_uint2(0u, REC_FILLER);
+#ifdef RT_WALK_STATS
+    if (lane == 0) {
+        atomicAdd(&A.cnt->walk_iters[ANY ? 1 : 0], st_iters);
+        atomicAdd(&A.cnt->walk_visits[ANY ? 1 : 0], st_visits);
+    }
+#endif
 #undef UNIFORM
 }
 
@@ -383,15 +402,13 @@ __global__ __launch_bounds__(256) void k_tri_test(WalkArgs A) {
         V3 ro, rd;
         uint32_t id = 0;
         if (ANY) {
-            const uint32_t q = rec.x;
-            id = A.shq.id[q];
+            const float4 o = A.shq.ray[2 * (size_t)rec.x], d = A.shq.ray[2 * (size_t)rec.x + 1];
+            id = __float_as_uint(o.w);
             if (A.cur.shadow[id >> 5] & (1u << (id & 31u))) continue;   // already known to be occluded
-            ro = v3(A.shq.ox[q], A.shq.oy[q], A.shq.oz[q]);
-            rd = v3(A.shq.dx[q], A.shq.dy[q], A.shq.dz[q]);
+            ro = v3(o.x, o.y, o.z);
+            rd = v3(d.x, d.y, d.z);
         } else {
-            const uint32_t i = rec.x;
-            ro = v3(A.cur.ox[i], A.cur.oy[i], A.cur.oz[i]);
-            rd = v3(A.cur.dx[i], A.cur.dy[i], A.cur.dz[i]);
+            load_ray(A.cur.ray, rec.x, ro, rd);
         }
         unsigned long long key = ~0ull;
         for (uint32_t k = 0; k < count; k++) {
@@ -462,7 +479,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
     const uint32_t i = in_range ? tid : 0;
     const uint32_t hp = A.cur.hp[i];
     const bool active = in_range && (hp >> 16) != 0xfffeu;
-    V3 ro = v3(A.cur.ox[i], A.cur.oy[i], A.cur.oz[i]), rd = v3(A.cur.dx[i], A.cur.dy[i], A.cur.dz[i]);
+    V3 ro, rd;
+    load_ray(A.cur.ray, i, ro, rd);
     // mesh hit of the closest-hit walk: it replaces the analytic hit only if strictly nearer (js/8-kd_tree.js:948-949)
     float ht = A.cur.ht[i];
     int32_t hf = A.cur.hf[i];
@@ -521,9 +539,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
         kd_mask &= kd_mask - 1;
         if (slot < A.shq_cap) {
             const V3 sd = shadow_dir(S, l, sf.point);
-            A.shq.ox[slot] = so.x; A.shq.oy[slot] = so.y; A.shq.oz[slot] = so.z;
-            A.shq.dx[slot] = sd.x; A.shq.dy[slot] = sd.y; A.shq.dz[slot] = sd.z;
-            A.shq.id[slot] = (tid << 5) | (uint32_t)l;
+            store_ray(A.shq.ray, slot, so, sd, (tid << 5) | (uint32_t)l);
         }
         slot++;
     }
@@ -538,7 +554,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_b(LevelArgs A) {
     const uint32_t i = in_range ? tid : 0;
     const uint32_t hp = A.cur.hp[i];
     const bool active = in_range && (hp >> 16) != 0xfffeu;
-    V3 ro = v3(A.cur.ox[i], A.cur.oy[i], A.cur.oz[i]), rd = v3(A.cur.dx[i], A.cur.dy[i], A.cur.dz[i]);
+    V3 ro, rd;
+    load_ray(A.cur.ray, i, ro, rd);
     Surface sf;
     const bool hit = active && make_surface(S, ro, rd, A.cur.ht[i], hp, A.cur.hf[i], sf);
     bool want_refl = false, want_refr = false;
@@ -620,15 +637,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade_b(LevelArgs A) {
         if (want_refr) {
             if (slot < A.nxt_cap) {
                 slot_refr = (int32_t)slot;
-                A.nxt.ox[slot] = c_refr_o.x; A.nxt.oy[slot] = c_refr_o.y; A.nxt.oz[slot] = c_refr_o.z;
-                A.nxt.dx[slot] = c_refr_d.x; A.nxt.dy[slot] = c_refr_d.y; A.nxt.dz[slot] = c_refr_d.z;
+                store_ray(A.nxt.ray, slot, c_refr_o, c_refr_d);
             }
             slot++;
         }
         if (want_refl && slot < A.nxt_cap) {
             slot_refl = (int32_t)slot;
-            A.nxt.ox[slot] = c_refl_o.x; A.nxt.oy[slot] = c_refl_o.y; A.nxt.oz[slot] = c_refl_o.z;
-            A.nxt.dx[slot] = c_refl_d.x; A.nxt.dy[slot] = c_refl_d.y; A.nxt.dz[slot] = c_refl_d.z;
+            store_ray(A.nxt.ray, slot, c_refl_o, c_refl_d);
         }
     }
     {   // shaded nodes of this level (shadow rays = shaded nodes x lights)
