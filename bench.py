@@ -105,6 +105,18 @@ def main():
     lvl_ms /= K
     stage_ms /= K
 
+    # the same frame with the canvas copied to a host buffer (what a caller without device memory pays);
+    # reported beside the metric, never as the metric
+    pcie_ms = None
+    if world == 1:
+        n_pcie = min(K, 5)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_pcie):
+            frame.step()
+            rt.readRGBA8()
+        pcie_ms = (time.perf_counter() - t1) / n_pcie * 1e3
+
     if rank != 0:
         comm.close()
         return
@@ -127,6 +139,8 @@ def main():
             "step": "rt_trace + luminance reduction" + (" + RCCL all-reduce + tile gather + assemble + present" if world > 1 else " + present"),
         },
         "mshadow_rays_per_s": shadow / (dt / K) / 1e6,
+        "pcie_inclusive": None if pcie_ms is None else {"ms_per_step": pcie_ms, "value": rays / (pcie_ms * 1e-3) / 1e6,
+                                                        "note": "step + rt_read_rgba8 of the 3840x2160 RGBA8 target into pageable host memory"},
         "trace_only_ms": trace_ms / K, "composite_ms": comp_ms / K, "tone_ms": tone_ms / K,
         "level_kernel_ms": [round(float(x), 4) for x in lvl_ms[:args.depth]],
         "stage_names": ["k_gen_prims", "k_kd_walk<closest>", "k_tri_test<closest>", "k_shade_a", "k_kd_walk<shadow>", "k_tri_test<shadow>", "k_shade_b"],

@@ -376,6 +376,8 @@ int rt_set_primitives(rt_ctx *ctx, const rt_prim *prims, int32_t n) {
     if (n > 60000) return fail(ctx, "rt_set_primitives: at most 60000 primitives");
     for (int i = 0; i < n; i++)
         if (prims[i].kind < RT_PRIM_PLANE || prims[i].kind > RT_PRIM_CYLINDER) return fail(ctx, "rt_set_primitives: unknown primitive kind");
+    // callers that mirror RayTracer.update set every table on every frame: an unchanged table costs nothing
+    if ((size_t)n == ctx->prims_host.size() && (n == 0 || memcmp(prims, ctx->prims_host.data(), (size_t)n * sizeof(rt_prim)) == 0)) return 0;
     ctx->prims_host.assign(prims, prims + n);
     ctx->scene_dirty = true;
     return 0;
@@ -386,6 +388,7 @@ int rt_set_materials(rt_ctx *ctx, const rt_material *mats, int32_t n) {
     if (n < 0 || (n > 0 && !mats)) return fail(ctx, "rt_set_materials: bad arguments");
     for (int i = 0; i < n; i++)
         if (mats[i].type < RT_MAT_PHONG || mats[i].type > RT_MAT_PHONG_CHECKERED) return fail(ctx, "rt_set_materials: unknown material type");
+    if ((size_t)n == ctx->mats_host.size() && (n == 0 || memcmp(mats, ctx->mats_host.data(), (size_t)n * sizeof(rt_material)) == 0)) return 0;
     ctx->mats_host.assign(mats, mats + n);
     ctx->scene_dirty = true;
     ctx->mesh_dirty = true;   // per-face material slots are resolved against this table

@@ -1,0 +1,77 @@
+'use strict';
+// Checks the JavaScript host against one golden fixture directory (tests/golden/<name>): every uniform the
+// reference handed to WebGL, the mesh arrays and the k-d tree export must match bit for bit.
+//   node check_golden.js <golden dir> [path of a page script whose generateScene() should be used]
+// Without the second argument the scene comes from examples/default_scene.js. Runs on a host-only context.
+const fs = require('fs');
+const path = require('path');
+const crypto = require('crypto');
+const rt = require('..');
+
+const dir = process.argv[2];
+const pageScript = process.argv[3];
+const man = JSON.parse(fs.readFileSync(path.join(dir, 'manifest.json'), 'utf8'));
+const sha = (ta) => crypto.createHash('sha256').update(Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength)).digest('hex');
+
+function extractGenerateScene(text) {
+    const start = text.indexOf('function generateScene(');
+    if (start < 0) throw new Error('no generateScene in ' + pageScript);
+    const end = text.indexOf('\n}\n', start);
+    return text.slice(start, end + 3);
+}
+
+const edits = man.constant_edits || {};
+const opts = { WIDTH: man.width, HEIGHT: man.height, DEVICE: -1 };
+for (const k of Object.keys(edits)) opts[k] = JSON.parse(edits[k]);
+const G = rt.createContext(opts);
+const source = pageScript ? extractGenerateScene(fs.readFileSync(pageScript, 'utf8'))
+    : fs.readFileSync(path.join(__dirname, '..', 'examples', 'default_scene.js'), 'utf8');
+rt.run(G, source, pageScript || 'default_scene.js');
+
+(async () => {
+    const failures = [];
+    const data = await G.loadPLY(G.MODEL_FILE_NAME);
+    const scene = G.generateScene({ [G.MODEL_FILE_NAME]: data });
+    G.animate(scene, man.time);
+    const tracer = new G.RayTracer();
+    tracer.setScene(scene);
+    tracer.prepare(man.time);
+
+    let checked = 0;
+    for (const u of man.uniforms) {
+        if (!(u.name in tracer.uniforms)) continue;
+        const v = tracer.uniforms[u.name];
+        let got;
+        if (v instanceof rt.THREE.Vector3) got = new Float32Array([v.x, v.y, v.z]);
+        else if (v instanceof rt.THREE.Matrix4) got = new Float32Array(v.toArray());
+        else got = new Float32Array([v]);
+        const want = new Float32Array(u.value);
+        checked++;
+        if (got.length !== want.length || !got.every((x, i) => Object.is(x, want[i]) || x === want[i])) {
+            failures.push('uniform ' + u.name + ': got [' + Array.from(got) + '] want [' + Array.from(want) + ']');
+        }
+    }
+    const expectNames = man.uniforms.map((u) => u.name).filter((n) => /^(model|invModel|phong|pointLights|ambientLight|bgColor|cameraPos|ray|kdBox)/.test(n));
+    for (const n of expectNames) if (!(n in tracer.uniforms)) failures.push('uniform ' + n + ' was not produced');
+
+    const k = tracer._meshKey;
+    const hashes = { verts_f64: sha(k.verts), verts_f32: sha(new Float32Array(k.verts)), faces_u32: sha(k.faces), face_mat_u32: sha(k.mats) };
+    // the reference stores (type, id, 0) per face in an RGB texture; the fixture hashes that 3-wide layout
+    const mat3 = new Uint32Array(k.mats.length / 2 * 3);
+    for (let i = 0; i < k.mats.length / 2; i++) { mat3[3 * i] = k.mats[2 * i]; mat3[3 * i + 1] = k.mats[2 * i + 1]; }
+    const hashes3 = sha(mat3);
+    for (const name of Object.keys(man.sha256)) {
+        if (!(name in hashes)) continue;
+        if (hashes[name] !== man.sha256[name] && !(name === 'face_mat_u32' && hashes3 === man.sha256[name])) failures.push('sha256 ' + name + ' differs');
+    }
+    const kd = tracer.exportKdTree();
+    if (kd.nodes.length / 2 !== man.kd.n_nodes) failures.push('k-d node count ' + kd.nodes.length / 2 + ' != ' + man.kd.n_nodes);
+    if (sha(kd.nodes) !== man.kd.sha256.nodes_sparse_u32) failures.push('k-d nodes differ');
+    if (sha(kd.leaves) !== man.kd.sha256.leaves_i32) failures.push('k-d leaves differ');
+    if (sha(kd.box) !== man.kd.sha256.root_box_f64) failures.push('k-d root box differs');
+
+    console.log(JSON.stringify({ golden: path.basename(dir), scene: pageScript ? 'page script' : 'example', uniforms_checked: checked,
+        n_verts: k.verts.length / 3, n_faces: k.faces.length / 3, kd_nodes: kd.nodes.length / 2, failures }));
+    tracer.dispose();
+    process.exit(failures.length ? 1 : 0);
+})().catch((e) => { console.error(e.stack || e); process.exit(2); });

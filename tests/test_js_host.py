@@ -1,0 +1,89 @@
+"""The JavaScript host (ray-tracer_amd/js): the reference's scene API + class RayTracer over the N-API addon.
+
+CPU: the checker script runs the scene through a host-only context and compares every uniform, the mesh arrays
+and the k-d export with the fixtures captured from the reference - first with the example scene description,
+then (when the reference checkout is present) with the reference's own, unmodified generateScene() text.
+GPU: one frame rendered from JavaScript must equal, byte for byte, the frame rendered through the Python binding.
+"""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, ROOT, make_flat
+
+JS = os.path.join(ROOT, "ray-tracer_amd", "js")
+ADDON = os.path.join(JS, "addon", "rt_addon.node")
+NODE = shutil.which("node")
+REF_SCRIPT = "/root/reference/js/8-kd_tree.js"
+
+needs_node = pytest.mark.skipif(NODE is None or not os.path.exists(ADDON), reason="node or the built addon is missing")
+
+
+def run_node(args, timeout=300):
+    p = subprocess.run([NODE] + args, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, "node %s failed:\n%s\n%s" % (" ".join(args), p.stdout[-2000:], p.stderr[-2000:])
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+@needs_node
+@pytest.mark.parametrize("golden", ["k8_res4_640x480", "k8_res3_640x480", "c2_res4_1920x1080", "k8_full_640x480"])
+def test_js_scene_matches_reference_capture(golden):
+    out = run_node([os.path.join(JS, "test", "check_golden.js"), os.path.join(GOLDEN, golden)])
+    assert out["failures"] == [] and out["uniforms_checked"] >= 80
+
+
+@needs_node
+@pytest.mark.skipif(not os.path.exists(REF_SCRIPT), reason="reference checkout not present")
+@pytest.mark.parametrize("golden", ["k8_res4_640x480", "c2_res4_1920x1080"])
+def test_unchanged_reference_generate_scene_runs(golden):
+    """generateScene() is read from the reference's page script at test time and evaluated as it is."""
+    out = run_node([os.path.join(JS, "test", "check_golden.js"), os.path.join(GOLDEN, golden), REF_SCRIPT])
+    assert out["failures"] == [] and out["scene"] == "page script"
+
+
+@needs_node
+def test_js_abstract_classes_and_errors():
+    code = r"""
+const rt = require(%r);
+const G = rt.createContext({DEVICE: -1});
+const msgs = [];
+for (const f of [() => new G.Primitive(0), () => new G.Material(0, 0), () => new G.Light(0), () => new G.Plane(0).scale(new G.THREE.Vector3(1,1,1)),
+                 () => new G.Sphere(1).intersect(null), () => new G.Phong(0,1,1,1,1,0,0,0,null,null).constructor.prototype.__proto__.setUniforms.call({}, {})]) {
+  try { f(); msgs.push(null); } catch (e) { msgs.push(e.message); }
+}
+let traceErr = null;
+try { const t = new G.RayTracer(); t.setScene({objects: [], materials: [], lights: [], ambientLight: new G.THREE.Vector3(), bgColor: new G.THREE.Vector3()}); t.update(0); }
+catch (e) { traceErr = e.message; }
+console.log(JSON.stringify({msgs, traceErr}));
+""" % JS
+    out = run_node(["-e", code])
+    assert out["msgs"] == ["Primitive: cannot instantiate abstract class.", "Material: cannot instantiate abstract class.",
+                           "Light: cannot instantiate abstract class.", "Plane: cannot call abstract method 'scale'",
+                           "Primitive: cannot call abstract method 'intersect'", "Material: cannot call abstract method 'setUniforms'"]
+    assert out["traceErr"] and "host-only" in out["traceErr"]   # no CPU fallback behind the JavaScript class either
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_render_equals_python_binding():
+    from ray_tracer_amd import abi
+    mm = (0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9)
+    out = run_node([os.path.join(JS, "examples", "render.js"), "--width", "640", "--height", "480", "--depth", "5",
+                    "--mesh-material", ",".join(str(v) for v in mm)])
+    flat = make_flat("bun_zipper_res4.ply", 640, 480, depth=5, mesh_material=mm)
+    rt = abi.RayTracerHIP(flat.cfg)
+    rt.setScene(flat)
+    rt.trace()
+    rgba = rt.readRGBA8()
+    Lbar, sf = rt.tone()
+    canvas = rt.present()
+    assert out["rgba8_sha256"] == hashlib.sha256(np.ascontiguousarray(rgba).tobytes()).hexdigest()
+    assert out["canvas_sha256"] == hashlib.sha256(np.ascontiguousarray(canvas).tobytes()).hexdigest()
+    assert out["Lbar"] == Lbar and out["sf"] == sf
+    assert out["rays"] == rt.stats().rays_total
+    rt.close()
