@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--time", type=float, default=0.0)
     ap.add_argument("--cpu-step", type=int, default=1, help="CPU baseline traces every n-th pixel in x and y")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
+    ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (rehearsal on a one-GPU box); default LOCAL_RANK")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,8 +67,11 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
 
     import torch
+    if args.device is not None:
+        local = args.device
     torch.cuda.set_device(local)
-    comm = multi_gpu.Comm(rank, world, local, backend="nccl") if world > 1 else multi_gpu.Comm(0, 1, local, backend=None)
+    comm = (multi_gpu.Comm(rank, world, local, backend=args.backend, device="cuda:%d" % local) if world > 1
+            else multi_gpu.Comm(0, 1, local, backend=None, device="cuda:%d" % local))
 
     sc = build_workload(args)
     cfg = abi.default_config(args.width, args.height, depth=args.depth, shard_index=rank, shard_count=world, device=local)

@@ -14,13 +14,15 @@ import numpy as np
 
 
 class Comm:
-    def __init__(self, rank, world, local_rank=0, backend="nccl"):
+    def __init__(self, rank, world, local_rank=0, backend="nccl", device=None):
+        """backend "nccl": collectives run on GPU tensors over RCCL. backend "gloo" with a cuda `device` is the
+        rehearsal mode (several ranks sharing one GPU, which RCCL refuses): tensors are staged through the host."""
         self.rank, self.world, self.local = rank, world, local_rank
         self.dist = None
-        self.device = "cpu"
+        self.device = device or "cpu"
+        self.backend = backend
         if backend == "nccl":
-            import torch
-            self.device = "cuda:%d" % local_rank
+            self.device = device or "cuda:%d" % local_rank
         if world > 1:
             import torch.distributed as dist
             if not dist.is_initialized():
@@ -35,9 +37,12 @@ class Comm:
         if not self.dist:
             return value
         import torch
-        t = torch.tensor([value], dtype=dtype, device=self.device)
+        t = torch.tensor([value], dtype=dtype, device=self._wire())
         self.dist.all_reduce(t, op=op)
         return t.item()
+
+    def _wire(self):
+        return self.device if self.backend == "nccl" else "cpu"
 
     def max_float(self, v):
         import torch.distributed as dist
@@ -54,7 +59,7 @@ class Comm:
         if not self.dist:
             return sum_log, count
         import torch
-        t = torch.tensor([sum_log, float(count)], dtype=torch.float64, device=self.device)
+        t = torch.tensor([sum_log, float(count)], dtype=torch.float64, device=self._wire())
         self.dist.all_reduce(t)
         s, n = t.tolist()
         return s, int(n)
@@ -65,12 +70,15 @@ class Comm:
         if not self.dist:
             return shard
         out = None
+        wire = shard if self.backend == "nccl" else shard.cpu()
         if self.rank == 0:
-            out = torch.empty(self.world * stride, dtype=torch.uint8, device=shard.device)
+            out = torch.empty(self.world * stride, dtype=torch.uint8, device=wire.device)
             parts = list(out.split(stride))
         else:
             parts = None
-        self.dist.gather(shard, gather_list=parts, dst=0)
+        self.dist.gather(wire, gather_list=parts, dst=0)
+        if out is not None and out.device != shard.device:
+            out = out.to(shard.device)
         return out
 
     def close(self):

@@ -1,0 +1,188 @@
+"""The N > 1 frame path (FrameJob + Comm) over gloo with two CPU ranks.
+
+Each rank runs the same FrameJob the GPU ranks run, with a stand-in shard that renders its interleaved 8x8 tiles
+with the oracle and lays them out exactly like rt_device_shard_rgba8 does ([tile][64 pixels][RGBA], alpha 0 for
+lanes outside the image). Rank 0 must end up with the full frame, and every rank with the full-image Lbar / sf.
+"""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+# spawned ranks import this module without conftest.py: make the package importable first
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (_ROOT, os.path.join(_ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+import rt_loader  # noqa: E402
+
+rt_loader.load()
+from helpers import make_flat  # noqa: E402
+
+W, H = 100, 60   # ragged on purpose: 13 x 8 tiles, the last column and row are partial
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class OracleShard:
+    def __init__(self, flat, rank, world):
+        from oracle import oracle
+        self.ora = oracle.OracleRenderer(flat)
+        self.rank, self.world = rank, world
+        self.tx, self.ty = (W + 7) // 8, (H + 7) // 8
+        self.tiles = list(range(rank, self.tx * self.ty, world))
+        self.stride = ((self.tx * self.ty + world - 1) // world) * 256
+        self.full = None
+        self.frame = None
+
+    def trace(self):
+        _, self.full, _, _ = self.ora.trace(threads=2, want_float=False, want_ids=False)
+
+    def _tile_pixels(self, t):
+        x0, y0 = (t % self.tx) * 8, (t // self.tx) * 8
+        for ly in range(8):
+            for lx in range(8):
+                yield ly * 8 + lx, x0 + lx, y0 + ly
+
+    def tone_partial(self):
+        s, n = 0.0, 0
+        for t in self.tiles:
+            for _, x, y in self._tile_pixels(t):
+                if x < W and y < H:
+                    r, g, b = (float(v) * 1000 / 256.0 for v in self.full[y, x, :3])
+                    s += math.log(0.0001 + (0.27 * r + 0.67 * g + 0.07 * b))
+                    n += 1
+        return s, n
+
+    def shard_bytes(self):
+        buf = np.zeros(self.stride, np.uint8)
+        for k, t in enumerate(self.tiles):
+            for lane, x, y in self._tile_pixels(t):
+                if x < W and y < H:
+                    buf[k * 256 + lane * 4:k * 256 + lane * 4 + 4] = self.full[y, x]
+        return torch.from_numpy(buf), self.stride
+
+    def assemble(self, gathered, stride, world):
+        g = gathered.numpy()
+        self.frame = np.zeros((H, W, 4), np.uint8)
+        for r in range(world):
+            for k, t in enumerate(range(r, self.tx * self.ty, world)):
+                for lane, x, y in self._tile_pixels(t):
+                    px = g[r * stride + k * 256 + lane * 4:r * stride + k * 256 + lane * 4 + 4]
+                    if x < W and y < H:
+                        assert px[3] == 255
+                        self.frame[y, x] = px
+                    else:
+                        assert px[3] == 0
+
+    def tone_finish(self, s, n):
+        Lbar = math.exp(s / n)
+        return Lbar, ((1.219 + (500 * 0.5) ** 0.4) / (1.219 + Lbar ** 0.4)) ** 2.5
+
+    def present(self):
+        pass
+
+
+def worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ray_tracer_amd import multi_gpu
+    flat = make_flat("bun_zipper_res4.ply", W, H, depth=2, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.0, 0.0))
+    comm = multi_gpu.Comm(rank, world, 0, backend="gloo")
+    shard = OracleShard(flat, rank, world)
+    job = multi_gpu.FrameJob(shard, comm)
+    Lbar, sf = job.step()
+    total_px = comm.sum_int(shard.tone_partial()[1])
+    tmax = comm.max_float(float(rank))
+    ok_frame = True
+    if rank == 0:
+        ok_frame = bool(np.array_equal(shard.frame, shard.full))
+    wl, ws = shard.ora.tone(shard.full)
+    out.put((rank, Lbar, sf, wl, ws, total_px, tmax, ok_frame))
+    comm.close()
+
+
+def test_frame_job_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == [0, 1]
+    for rank, Lbar, sf, wl, ws, total_px, tmax, ok_frame in results:
+        assert total_px == W * H            # every pixel belongs to exactly one rank
+        assert tmax == 1.0
+        assert ok_frame                      # rank 0 reassembled the whole frame from the gathered tiles
+        assert abs(Lbar - wl) <= 1e-12 * wl and abs(sf - ws) <= 1e-12 * ws   # all-reduced sums = whole-image statistic
+    assert results[0][1] == results[1][1]    # both ranks hold the same Lbar
+
+
+# ---- the same job with the HIP shards: two ranks share GPU 0, tensors staged through gloo ------------------
+import pytest  # noqa: E402
+
+
+def hip_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import hashlib
+    from ray_tracer_amd import abi, multi_gpu
+    torch.cuda.set_device(0)
+    flat = make_flat("bun_zipper_res4.ply", 324, 243, depth=3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9),
+                     shard_index=rank, shard_count=world)
+    rt = abi.RayTracerHIP(flat.cfg)
+    rt.setScene(flat)
+    comm = multi_gpu.Comm(rank, world, 0, backend="gloo", device="cuda:0")
+    job = multi_gpu.FrameJob(rt, comm)
+    for _ in range(2):
+        Lbar, sf = job.step()
+    res = {"rank": rank, "Lbar": Lbar, "sf": sf, "rays": int(rt.stats().rays_total)}
+    if rank == 0:
+        res["rgba"] = hashlib.sha256(np.ascontiguousarray(rt.readRGBA8()).tobytes()).hexdigest()
+        p, n = abi.C.c_void_p(), abi.C.c_size_t()
+        rt._ck(rt.L.rt_device_canvas(rt.ctx, abi.C.byref(p), abi.C.byref(n)), "rt_device_canvas")
+        canvas = torch.as_tensor(multi_gpu._DevView(p.value, n.value), device="cuda:0").cpu().numpy()
+        res["canvas"] = hashlib.sha256(canvas.tobytes()).hexdigest()
+    out.put(res)
+    comm.close()
+    rt.close()
+
+
+@pytest.mark.gpu
+def test_two_hip_shards_equal_one_context():
+    import hashlib
+    from ray_tracer_amd import abi
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=hip_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r["rank"]: r for r in (q.get(timeout=240) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    flat = make_flat("bun_zipper_res4.ply", 324, 243, depth=3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    rt = abi.RayTracerHIP(flat.cfg)
+    rt.setScene(flat)
+    rt.trace()
+    Lbar, sf = rt.tone()
+    canvas = rt.present()
+    assert results[0]["rgba"] == hashlib.sha256(np.ascontiguousarray(rt.readRGBA8()).tobytes()).hexdigest()
+    assert results[0]["canvas"] == hashlib.sha256(np.ascontiguousarray(canvas).tobytes()).hexdigest()
+    assert results[0]["rays"] + results[1]["rays"] == rt.stats().rays_total
+    for r in results.values():
+        assert abs(r["Lbar"] - Lbar) <= 1e-10 * Lbar and np.float32(r["sf"]) == np.float32(sf)
+    rt.close()
