@@ -64,7 +64,7 @@ struct rt_ctx {
     size_t cap_prims = 0, cap_mats = 0, cap_lights = 0, cap_tris = 0, cap_nodes = 0, cap_ltris = 0;
     Level lv[MAX_LEVELS];
     LevelCounters *d_counts = nullptr;           // one block of counters per level
-    uint32_t *d_kdq = nullptr;                   // closest-hit traversal queue (ray indices), reused by every level
+    uint4 *d_kdq = nullptr;                      // closest-hit traversal queue, reused by every level
     void *d_shq_mem = nullptr;                   // shadow traversal queue, reused by every level
     ShadowQ shq{};
     size_t cap_kdq = 0;
@@ -147,6 +147,7 @@ int ensure_queues(rt_ctx *ctx, uint32_t n_rays, uint32_t n_lights) {
     HIPCK(hipMalloc(&ctx->d_shq_mem, (size_t)cap * SHADOWQ_ARRAYS * sizeof(float)));
     ctx->cap_shq = cap;
     ctx->shq.ray = (float4 *)ctx->d_shq_mem;
+    ctx->shq.id = (uint32_t *)((float *)ctx->d_shq_mem + 8 * (size_t)cap);
     return 0;
 }
 

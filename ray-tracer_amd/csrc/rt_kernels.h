@@ -48,9 +48,10 @@ struct LevelBuf {
 constexpr int LEVEL_ARRAYS = 21;        // 32-bit words per ray
 
 struct ShadowQ {                         // shadow rays that must walk the k-d tree
-    float4 *ray;                         // ray[2q] = origin, w = bits of (ray index << 5 | light); ray[2q+1] = direction
+    float4 *ray;                         // ray[2q] = origin, w = entry distance of the root box; ray[2q+1] = direction, w = exit distance
+    uint32_t *id;                        // ray index << 5 | light
 };
-constexpr int SHADOWQ_ARRAYS = 8;
+constexpr int SHADOWQ_ARRAYS = 9;
 constexpr int MAX_LIGHTS = 32;
 
 struct FrameGeom {
@@ -76,7 +77,7 @@ struct LevelArgs {
     SceneDev S;             // by value: lands in the kernel-argument segment, read through scalar loads
     LevelBuf cur, nxt;
     ShadowQ shq;
-    uint32_t *kdq;          // ray indices for the closest-hit traversal
+    uint4 *kdq;             // closest-hit traversal queue: (ray index, root-box entry distance, exit distance, -)
     const uint2 *recs;      // triangle records of the closest walk (k_shade_a resolves the winner)
     LevelCounters *cnt;
     uint32_t n_rays, nxt_cap, shq_cap, rec_cap;
@@ -106,9 +107,9 @@ __device__ __forceinline__ void load_ray(const float4 *ray, uint32_t i, V3 &ro, 
     ro = v3(o.x, o.y, o.z);
     rd = v3(d.x, d.y, d.z);
 }
-__device__ __forceinline__ void store_ray(float4 *ray, uint32_t i, V3 ro, V3 rd, uint32_t tag = 0u) {
-    ray[2 * (size_t)i] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(tag));
-    ray[2 * (size_t)i + 1] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+__device__ __forceinline__ void store_ray(float4 *ray, uint32_t i, V3 ro, V3 rd, float w0 = 0.0f, float w1 = 0.0f) {
+    ray[2 * (size_t)i] = make_float4(ro.x, ro.y, ro.z, w0);
+    ray[2 * (size_t)i + 1] = make_float4(rd.x, rd.y, rd.z, w1);
 }
 
 // Reserves `c` consecutive slots per lane in a global queue with ONE atomic per workgroup (an atomic per
@@ -138,10 +139,12 @@ __device__ __forceinline__ uint32_t block_reserve(uint32_t c, uint32_t *counter,
     return r;
 }
 
-__device__ __forceinline__ bool enters_box(const SceneDev &S, V3 ro, V3 rd) {
-    float tmin, tmax;
+// root-box interval of a ray (js/8-kd_tree.js:545-573); the walk is needed when it is not empty: the reference's
+// `while (kdTMax < maxDist)` then runs at least once. The interval travels with the queue entry, so that a walking
+// lane picks up a new ray without any arithmetic.
+__device__ __forceinline__ bool enters_box(const SceneDev &S, V3 ro, V3 rd, float &tmin, float &tmax) {
     ray_box(S, ro, rd, tmin, tmax);
-    return tmin < tmax;   // the reference's `while (kdTMax < maxDist)` runs at least once
+    return tmin < tmax;
 }
 
 // ---- stage 1 -----------------------------------------------------------------------------------
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
     uint32_t best = 0xffffu, last = 0xffffu;
     int32_t face = -1;
     bool to_kd = false;
+    float kd_t0 = 0.0f, kd_t1 = 0.0f;
     if (active) {
         // analytic primitives in scene order, strict `t < tMin` (js/8-kd_tree.js:1202-1214)
         for (int i = 0; i < S.n_prims; i++) {
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
         }
         if (S.render_triangles) {
             if (S.use_kd) {
-                to_kd = enters_box(S, ro, rd);
+                to_kd = enters_box(S, ro, rd, kd_t0, kd_t1);
             } else {
                 for (int f = 0; f < S.n_faces; f++) {   // USE_KD_TREE = false: every face (js/8-kd_tree.js:965-988)
                     float t;
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
         A.cur.best[tid] = ~0ull;
     }
     const uint32_t slot = block_reserve(to_kd ? 1u : 0u, &A.cnt->kdq_count, s_wave);
-    if (to_kd) A.kdq[slot] = tid;
+    if (to_kd) A.kdq[slot] = make_uint4(tid, __float_as_uint(kd_t0), __float_as_uint(kd_t1), 0u);
 }
 
 // ---- k-d walk ----------------------------------------------------------------------------------------
@@ -216,7 +220,7 @@ struct WalkArgs {
     SceneDev S;
     LevelBuf cur;
     ShadowQ shq;
-    const uint32_t *kdq;
+    const uint4 *kdq;
     uint2 *recs;            // out: (ray reference, leaf face count << 27 | first slot in S.ltris)
     LevelCounters *cnt;
     uint32_t shq_cap, rec_cap;
@@ -237,7 +241,13 @@ struct WalkArgs {
 #define RT_WALK_WAVES_PER_CU 24
 #endif
 constexpr int REFILL_MIN_IDLE = RT_REFILL_MIN_IDLE;   // refill once this many lanes of the wave have no ray
-constexpr int REFILL_CHUNK = 256;                    // rays a wave reserves from the global queue per atomic
+#ifndef RT_REFILL_CHUNK
+#define RT_REFILL_CHUNK 64
+#endif
+// a refill hands out up to one ray per lane from a single reservation, so a chunk must cover a whole wave; a
+// smaller chunk would let the wave's cursor run past its reservation and the wave would never see the queue end
+static_assert(RT_REFILL_CHUNK >= 64, "REFILL_CHUNK must be at least the wave size");
+constexpr int REFILL_CHUNK = RT_REFILL_CHUNK;                    // rays a wave reserves from the global queue per atomic
 #ifndef RT_REC_CHUNK
 #define RT_REC_CHUNK 512
 #endif
@@ -276,13 +286,13 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
 
     for (;;) {
         // ---- refill: while the global queue has rays, as soon as enough lanes are free
-        const unsigned long long idle = __ballot(!walking);
-        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!walking);
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
         if (n_idle >= (uint32_t)REFILL_MIN_IDLE) {
             if (!more) {
                 if (n_idle == (uint32_t)WAVE) break;
             } else {
-                const uint32_t rank = (uint32_t)__popcll(idle & below);
+                const uint32_t rank = (uint32_t)__builtin_popcountll(idle & below);
                 const uint32_t left = chunk_end - chunk_pos;
                 uint32_t q;
                 if (left < n_idle) {
@@ -299,19 +309,27 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
                     chunk_pos += n_idle;
                 }
                 if (!walking && q < total) {
-                    ref = ANY ? q : A.kdq[q];
-                    const float4 *rp = (ANY ? A.shq.ray : A.cur.ray) + 2 * (size_t)ref;
-                    const float4 fo = rp[0], fd = rp[1];
-                    ox = fo.x; oy = fo.y; oz = fo.z;
-                    dx = fd.x; dy = fd.y; dz = fd.z;
-                    ray_box(S, v3(ox, oy, oz), v3(dx, dy, dz), tmin, maxDist);
+                    if (ANY) {
+                        ref = q;
+                        const float4 fo = A.shq.ray[2 * (size_t)q], fd = A.shq.ray[2 * (size_t)q + 1];
+                        ox = fo.x; oy = fo.y; oz = fo.z; tmin = fo.w;
+                        dx = fd.x; dy = fd.y; dz = fd.z; maxDist = fd.w;
+                    } else {
+                        const uint4 e = A.kdq[q];
+                        ref = e.x;
+                        tmin = __uint_as_float(e.y);
+                        maxDist = __uint_as_float(e.z);
+                        const float4 fo = A.cur.ray[2 * (size_t)ref], fd = A.cur.ray[2 * (size_t)ref + 1];
+                        ox = fo.x; oy = fo.y; oz = fo.z;
+                        dx = fd.x; dy = fd.y; dz = fd.z;
+                    }
                     tmax = maxDist;
                     sp_top = sp_cnt = 0;
                     info = root.info;
                     split = root.split;
                     walking = tmin < maxDist;   // always true for queued rays; keeps the walk self-contained
                 }
-                if (!__any(walking)) continue;
+                if (__builtin_amdgcn_ballot_w64(walking) == 0ull) continue;
             }
         }
 
@@ -356,9 +374,9 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
         // ---- list the leaves just visited: one record (ray, leaf's slot range) per non-empty leaf; records of
         //      one ray only ever move forward in the buffer, so the buffer order is the visit order
         {
-            const unsigned long long m = __ballot(leaf_info != 0u);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(leaf_info != 0u);
             if (m) {
-                const uint32_t tot = (uint32_t)__popcll(m);
+                const uint32_t tot = (uint32_t)__builtin_popcountll(m);
                 if (rec_end - rec_pos < tot) {
                     for (uint32_t p = rec_pos + lane; p < rec_end; p += WAVE) A.recs[p] = make_uint2(0u, REC_FILLER);
                     uint32_t base = 0;
@@ -370,7 +388,7 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
                     rec_end = (base + (uint32_t)REC_CHUNK <= A.rec_cap) ? base + (uint32_t)REC_CHUNK : base;
                 }
                 if (rec_end - rec_pos >= tot) {
-                    if (leaf_info) A.recs[rec_pos + (uint32_t)__popcll(m & below)] = make_uint2(ref, leaf_info);
+                    if (leaf_info) A.recs[rec_pos + (uint32_t)__builtin_popcountll(m & below)] = make_uint2(ref, leaf_info);
                     rec_pos += tot;
                 }
             }
@@ -402,9 +420,9 @@ __global__ __launch_bounds__(256) void k_tri_test(WalkArgs A) {
         V3 ro, rd;
         uint32_t id = 0;
         if (ANY) {
-            const float4 o = A.shq.ray[2 * (size_t)rec.x], d = A.shq.ray[2 * (size_t)rec.x + 1];
-            id = __float_as_uint(o.w);
+            id = A.shq.id[rec.x];
             if (A.cur.shadow[id >> 5] & (1u << (id & 31u))) continue;   // already known to be occluded
+            const float4 o = A.shq.ray[2 * (size_t)rec.x], d = A.shq.ray[2 * (size_t)rec.x + 1];
             ro = v3(o.x, o.y, o.z);
             rd = v3(d.x, d.y, d.z);
         } else {
@@ -520,7 +538,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
             }
             if (!occluded && S.render_triangles) {
                 if (S.use_kd) {
-                    if (enters_box(S, so, sd)) kd_mask |= 1u << l;
+                    float t0, t1;
+                    if (enters_box(S, so, sd, t0, t1)) kd_mask |= 1u << l;
                 } else {
                     for (int f = 0; f < S.n_faces && !occluded; f++) {
                         float t;
@@ -539,7 +558,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
         kd_mask &= kd_mask - 1;
         if (slot < A.shq_cap) {
             const V3 sd = shadow_dir(S, l, sf.point);
-            store_ray(A.shq.ray, slot, so, sd, (tid << 5) | (uint32_t)l);
+            float t0, t1;
+            ray_box(S, so, sd, t0, t1);
+            store_ray(A.shq.ray, slot, so, sd, t0, t1);
+            A.shq.id[slot] = (tid << 5) | (uint32_t)l;
         }
         slot++;
     }
