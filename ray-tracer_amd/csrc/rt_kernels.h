@@ -266,18 +266,21 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
     uint32_t *head = ANY ? &A.cnt->shq_head : &A.cnt->kdq_head;
     uint32_t *rec_count = &A.cnt->rec_count[ANY ? 1 : 0];
     const KdNodeDev root = nodes[0];
-    const unsigned long long below = (1ull << lane) - 1ull;
 
     // wave-uniform values are passed through readfirstlane so that they live in scalar registers and
     // conditions on them compile to scalar branches instead of lane-mask arithmetic
 #define UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-    bool walking = false;
+    // rank of this lane among the set bits of a wave mask
+    // 32-bit population count of a wave mask (a 64-bit count would drag 64-bit compares, which have no scalar form)
+#define COUNT_OF(mask) ((uint32_t)__builtin_popcount((uint32_t)(mask)) + (uint32_t)__builtin_popcount((uint32_t)((mask) >> 32)))
+#define RANK_IN(mask) __builtin_amdgcn_mbcnt_hi((uint32_t)((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mask), 0u))
     uint32_t more = 1u;                      // wave-uniform: the global queue may still hold rays
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
     float tmin = 0.0f, tmax = 0.0f, maxDist = 0.0f;
-    uint32_t ref = 0, info = 0;
+    uint32_t ref = 0;
+    uint32_t info = 0;                       // node the lane stands on; 0 (no node has it) = the lane has no ray
     float split = 0.0f;
-    uint32_t sp_top = 0, sp_cnt = 0;
+    int32_t sp_top = 0, sp_lo = 0;           // ring stack: entries sp_lo .. sp_top-1 are valid (at most SHORT_STACK)
     uint32_t chunk_pos = 0, chunk_end = 0;   // wave-uniform: rays reserved from the global queue
     uint32_t rec_pos = 0, rec_end = 0;       // wave-uniform: record slots reserved in A.recs
 #ifdef RT_WALK_STATS
@@ -286,13 +289,13 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
 
     for (;;) {
         // ---- refill: while the global queue has rays, as soon as enough lanes are free
-        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!walking);
-        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(info == 0u);
+        const uint32_t n_idle = COUNT_OF(idle);
         if (n_idle >= (uint32_t)REFILL_MIN_IDLE) {
-            if (!more) {
+            if (!UNIFORM(more)) {
                 if (n_idle == (uint32_t)WAVE) break;
             } else {
-                const uint32_t rank = (uint32_t)__builtin_popcountll(idle & below);
+                const uint32_t rank = RANK_IN(idle);
                 const uint32_t left = chunk_end - chunk_pos;
                 uint32_t q;
                 if (left < n_idle) {
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
                     q = chunk_pos + rank;
                     chunk_pos += n_idle;
                 }
-                if (!walking && q < total) {
+                if (info == 0u && q < total) {
                     if (ANY) {
                         ref = q;
                         const float4 fo = A.shq.ray[2 * (size_t)q], fd = A.shq.ray[2 * (size_t)q + 1];
@@ -324,24 +327,24 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
                         dx = fd.x; dy = fd.y; dz = fd.z;
                     }
                     tmax = maxDist;
-                    sp_top = sp_cnt = 0;
-                    info = root.info;
+                    sp_top = sp_lo = 0;
                     split = root.split;
-                    walking = tmin < maxDist;   // always true for queued rays; keeps the walk self-contained
+                    info = tmin < maxDist ? root.info : 0u;   // always the root for queued rays; keeps the walk self-contained
                 }
-                if (__builtin_amdgcn_ballot_w64(walking) == 0ull) continue;
+                if (__builtin_amdgcn_ballot_w64(info != 0u) == 0ull) continue;
             }
         }
 
         // ---- one tree action per walking lane, written as straight-line predicated code: nested branches cost
-        //      a handful of scalar exec-mask instructions each, and the scalar unit is shared by the whole CU
+        //      a handful of scalar exec-mask instructions each, and a CU issues only about 1.5 instructions per
+        //      cycle whatever their kind, so the instruction count of this block is what the walk costs.
+        //      info: [31:30] type (1 internal, 2 empty leaf, 3 leaf) - the sign bit says "leaf of either kind"
 #ifdef RT_WALK_STATS
         st_iters++;
-        st_visits += (unsigned long long)__popcll(__ballot(walking));
+        st_visits += (unsigned long long)__popcll(__ballot(info != 0u));
 #endif
-        const uint32_t type = info >> 30;
-        const bool is_int = walking && type == 1u;
-        const bool at_leaf = walking && type != 1u;
+        const bool at_leaf = (int32_t)info < 0;
+        const bool is_int = info != 0u && !at_leaf;
         // internal node: classify the children and pick the side(s) the ray interval touches
         const uint32_t a = (info >> 28) & 3u;
         const float o = a == 0u ? ox : (a == 1u ? oy : oz), d = a == 0u ? dx : (a == 1u ? dy : dz);
@@ -352,20 +355,22 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
         const bool ge = t >= tmax, le = t <= tmin;
         const bool both = is_int && !ge && !le;
         uint32_t next = (le && !ge) ? farc : nearc;
-        if (both) stack[(sp_top & (SHORT_STACK - 1)) * WAVE] = make_uint2(farc, __float_as_uint(tmax));
-        // leaf (or empty leaf): list it, then go on with the next cell of the ray
-        const uint32_t leaf_info = (at_leaf && type == 3u LEAF_EMIT_COND) ? (info & 0x3fffffffu) : 0u;
+        if (both) stack[((uint32_t)sp_top & (SHORT_STACK - 1)) * WAVE] = make_uint2(farc, __float_as_uint(tmax));
+        // leaf (or empty leaf): list it (below), then go on with the next cell of the ray
+        const bool is_listed = info >= 0xc0000000u LEAF_EMIT_COND;
+        const unsigned long long listed = __builtin_amdgcn_ballot_w64(is_listed);
+        const uint32_t leaf_info = info & 0x3fffffffu;
         const bool cont = at_leaf && tmax < maxDist;   // false on the last cell and on a NaN interval
-        const bool pop = cont && sp_cnt != 0u;
+        const bool pop = cont && sp_top != sp_lo;
         uint2 e = make_uint2(0u, __float_as_uint(maxDist));   // ring ran dry: restart at the root up to maxDist
-        if (pop) e = stack[((sp_top - 1u) & (SHORT_STACK - 1)) * WAVE];
-        sp_top = sp_top + (both ? 1u : 0u) - (pop ? 1u : 0u);
-        sp_cnt = both ? (sp_cnt < (uint32_t)SHORT_STACK ? sp_cnt + 1u : sp_cnt) : (pop ? sp_cnt - 1u : sp_cnt);
+        if (pop) e = stack[((uint32_t)(sp_top - 1) & (SHORT_STACK - 1)) * WAVE];
+        sp_top += both ? 1 : (pop ? -1 : 0);                  // a push and a pop never meet in one action
+        sp_lo = max(sp_lo, sp_top - SHORT_STACK);             // a push onto a full ring drops the oldest entry
         tmin = cont ? tmax : tmin;
         tmax = cont ? __uint_as_float(e.y) : (both ? t : tmax);
         next = cont ? e.x : next;
-        walking = walking && (is_int || cont);
-        if (walking) {
+        info = 0u;
+        if (is_int || cont) {
             const KdNodeDev n = nodes[next];
             info = n.info;
             split = n.split;
@@ -373,24 +378,21 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
 
         // ---- list the leaves just visited: one record (ray, leaf's slot range) per non-empty leaf; records of
         //      one ray only ever move forward in the buffer, so the buffer order is the visit order
-        {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(leaf_info != 0u);
-            if (m) {
-                const uint32_t tot = (uint32_t)__builtin_popcountll(m);
-                if (rec_end - rec_pos < tot) {
-                    for (uint32_t p = rec_pos + lane; p < rec_end; p += WAVE) A.recs[p] = make_uint2(0u, REC_FILLER);
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(rec_count, (uint32_t)REC_CHUNK);
-                    base = UNIFORM(base);
-                    rec_pos = base;
-                    // past the capacity nothing is written; the host sees rec_count > capacity and repeats
-                    // the level with a larger buffer
-                    rec_end = (base + (uint32_t)REC_CHUNK <= A.rec_cap) ? base + (uint32_t)REC_CHUNK : base;
-                }
-                if (rec_end - rec_pos >= tot) {
-                    if (leaf_info) A.recs[rec_pos + (uint32_t)__builtin_popcountll(m & below)] = make_uint2(ref, leaf_info);
-                    rec_pos += tot;
-                }
+        if (listed) {
+            const uint32_t tot = COUNT_OF(listed);
+            if (rec_end - rec_pos < tot) {
+                for (uint32_t p = rec_pos + lane; p < rec_end; p += WAVE) A.recs[p] = make_uint2(0u, REC_FILLER);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(rec_count, (uint32_t)REC_CHUNK);
+                base = UNIFORM(base);
+                rec_pos = base;
+                // past the capacity nothing is written; the host sees rec_count > capacity and repeats
+                // the level with a larger buffer
+                rec_end = (base + (uint32_t)REC_CHUNK <= A.rec_cap) ? base + (uint32_t)REC_CHUNK : base;
+            }
+            if (rec_end - rec_pos >= tot) {
+                if (is_listed) A.recs[rec_pos + RANK_IN(listed)] = make_uint2(ref, leaf_info);
+                rec_pos += tot;
             }
         }
     }
@@ -401,6 +403,8 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
         atomicAdd(&A.cnt->walk_visits[ANY ? 1 : 0], st_visits);
     }
 #endif
+#undef RANK_IN
+#undef COUNT_OF
 #undef UNIFORM
 }
 
