@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--time", type=float, default=0.0)
     ap.add_argument("--cpu-step", type=int, default=1, help="CPU baseline traces every n-th pixel in x and y")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--emulate-shards", type=int, default=0, help="single rank only: trace shard 0 of N (what one GPU of an N-GPU job does, without the exchange)")
+    ap.add_argument("--parts", type=int, default=0, help="concurrent slices per GPU (0 = library default)")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (rehearsal on a one-GPU box); default LOCAL_RANK")
     args = ap.parse_args()
@@ -74,7 +76,9 @@ def main():
             else multi_gpu.Comm(0, 1, local, backend=None, device="cuda:%d" % local))
 
     sc = build_workload(args)
-    cfg = abi.default_config(args.width, args.height, depth=args.depth, shard_index=rank, shard_count=world, device=local)
+    shard_count = args.emulate_shards if (world == 1 and args.emulate_shards > 1) else world
+    cfg = abi.default_config(args.width, args.height, depth=args.depth, shard_index=rank, shard_count=shard_count, device=local,
+                             parts=args.parts)
     flat = abi.FlatScene(sc, cfg, scene.camera_rays(args.width, args.height))
     rt = abi.RayTracerHIP(cfg)
     t0 = time.perf_counter()

@@ -62,7 +62,10 @@ typedef struct rt_config {
     int32_t shard_count;
     int32_t device;              /* HIP device ordinal; -1 = host-only context (mesh, k-d build and
                                     export work, every entry point that needs a GPU fails) */
-    int32_t reserved;
+    /* the shard is traced as `parts` independent slices of its tiles on separate HIP streams, so that the
+     * end of one slice's kernels (a few long rays) overlaps the other slices' work. 0 = library default
+     * (environment RT_PARTS, else 2); 1 = one stream. The image does not depend on it. No counterpart in the reference. */
+    int32_t parts;
 } rt_config;
 
 /* One analytic primitive = the two mat4 uniforms `model<i>` / `invModel<i>` plus the

@@ -21,7 +21,7 @@ class Config(C.Structure):
                 ("epsilon", C.c_float), ("sphere_epsilon", C.c_float), ("plane_rect_epsilon", C.c_float),
                 ("triangle_epsilon", C.c_float),
                 ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("device", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("parts", C.c_int32)]
 
 
 class Prim(C.Structure):
@@ -54,7 +54,7 @@ def default_config(width=640, height=480, depth=1, supersampling=1, **kw):
     c = Config(width=width, height=height, supersampling=supersampling, max_depth=depth, tr_method=0,
                render_triangles=1, use_kd_tree=1, max_kd_depth=24, L_max=1000.0, L_dmax=500.0, A=0.18,
                infinity=100000.0, epsilon=0.0001, sphere_epsilon=0.095, plane_rect_epsilon=0.095,
-               triangle_epsilon=0.0001, shard_index=0, shard_count=1, device=0, reserved=0)
+               triangle_epsilon=0.0001, shard_index=0, shard_count=1, device=0, parts=0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

@@ -31,15 +31,43 @@ struct Level {
     LevelBuf b{};
 };
 
+constexpr int MAX_PARTS = 8;
+
+// One independent slice of the shard's tiles. Every part has its own stream, ray-tree levels, queues, record
+// buffer and counters, so the parts of a frame run concurrently: while the last long rays of one part's walk
+// drain (a persistent kernel ends only when its slowest ray does), the other parts' kernels fill the machine.
+struct Part {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[MAX_LEVELS][N_STAGES + 1]{};   // stage boundaries of every level
+    hipEvent_t ev_begin = nullptr, ev_comp = nullptr, ev_end = nullptr;
+    Level lv[MAX_LEVELS];
+    LevelCounters *d_counts = nullptr;           // one block of counters per level
+    LevelCounters *h_counts = nullptr;           // pinned host copy
+    uint4 *d_kdq = nullptr;                      // closest-hit traversal queue, reused by every level
+    size_t cap_kdq = 0;
+    void *d_shq_mem = nullptr;                   // shadow traversal queue, reused by every level
+    ShadowQ shq{};
+    uint32_t cap_shq = 0;
+    uint2 *d_recs = nullptr;                     // triangle records of the walk in flight, reused by every level
+    size_t cap_recs = 0;
+    uint32_t n_rays[MAX_LEVELS]{};
+    FrameGeom g{};
+    uint32_t n0 = 0;                             // level-0 entries = tiles of this part * 64
+    int levels_run = 0;
+    int pending = -1;                            // level launched and not yet collected, -1 = none
+    int attempt = 0;
+};
+
 }  // namespace
 
 struct rt_ctx {
     rt_config cfg{};
     std::string err;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[MAX_LEVELS][N_STAGES + 1]{};   // stage boundaries of every level
-    hipEvent_t ev_misc[4]{};                     // frame begin / composite begin / frame end / spare
+    hipStream_t stream = nullptr;                // scene uploads, tone, present (= the first part's stream)
+    hipEvent_t ev_misc[2]{};                     // tone begin / end
     int n_cus = 256;
+    int n_parts = 1;
+    Part parts[MAX_PARTS];
     // scene (host copies)
     std::vector<PrimDev> prims;
     std::vector<rt_material> mats_host;
@@ -62,18 +90,8 @@ struct rt_ctx {
     TriDev *d_ltris = nullptr;
     bool tree_dirty = true;
     size_t cap_prims = 0, cap_mats = 0, cap_lights = 0, cap_tris = 0, cap_nodes = 0, cap_ltris = 0;
-    Level lv[MAX_LEVELS];
-    LevelCounters *d_counts = nullptr;           // one block of counters per level
-    uint4 *d_kdq = nullptr;                      // closest-hit traversal queue, reused by every level
-    void *d_shq_mem = nullptr;                   // shadow traversal queue, reused by every level
-    ShadowQ shq{};
-    size_t cap_kdq = 0;
-    uint2 *d_recs = nullptr;                     // triangle records of the walk in flight, reused by every level
-    size_t cap_recs = 0;
-    uint32_t cap_shq = 0;
-    uint32_t n_rays[MAX_LEVELS]{};
     // frame
-    FrameGeom g{};
+    FrameGeom g{};                               // the whole shard
     uint32_t n0 = 0;                             // level-0 entries = tiles of this shard * 64
     float *d_fb = nullptr;
     uint32_t *d_rgba = nullptr, *d_compact = nullptr, *d_canvas = nullptr;
@@ -114,8 +132,8 @@ int ensure(rt_ctx *ctx, T *&ptr, size_t &cap, size_t n) {
     return 0;
 }
 
-int ensure_level(rt_ctx *ctx, int l, uint32_t cap) {
-    Level &L = ctx->lv[l];
+int ensure_level(rt_ctx *ctx, Part &P, int l, uint32_t cap) {
+    Level &L = P.lv[l];
     if (L.mem && L.cap >= cap) return 0;
     if (L.mem) HIPCK(hipFree(L.mem));
     L.mem = nullptr;
@@ -136,18 +154,18 @@ int ensure_level(rt_ctx *ctx, int l, uint32_t cap) {
 }
 
 // traversal queues are shared by all levels: sized for the largest level seen so far
-int ensure_queues(rt_ctx *ctx, uint32_t n_rays, uint32_t n_lights) {
-    if (ensure(ctx, ctx->d_kdq, ctx->cap_kdq, n_rays)) return -1;
+int ensure_queues(rt_ctx *ctx, Part &P, uint32_t n_rays, uint32_t n_lights) {
+    if (ensure(ctx, P.d_kdq, P.cap_kdq, n_rays)) return -1;
     uint64_t want = (uint64_t)n_rays * std::max<uint32_t>(n_lights, 1);
     if (want > 0x7fffff00ull) return fail(ctx, "shadow queue too large");
-    if (ctx->d_shq_mem && ctx->cap_shq >= want) return 0;
-    if (ctx->d_shq_mem) HIPCK(hipFree(ctx->d_shq_mem));
-    ctx->d_shq_mem = nullptr;
+    if (P.d_shq_mem && P.cap_shq >= want) return 0;
+    if (P.d_shq_mem) HIPCK(hipFree(P.d_shq_mem));
+    P.d_shq_mem = nullptr;
     uint32_t cap = std::max<uint32_t>(((uint32_t)want + 255u) & ~255u, 256u);
-    HIPCK(hipMalloc(&ctx->d_shq_mem, (size_t)cap * SHADOWQ_ARRAYS * sizeof(float)));
-    ctx->cap_shq = cap;
-    ctx->shq.ray = (float4 *)ctx->d_shq_mem;
-    ctx->shq.id = (uint32_t *)((float *)ctx->d_shq_mem + 8 * (size_t)cap);
+    HIPCK(hipMalloc(&P.d_shq_mem, (size_t)cap * SHADOWQ_ARRAYS * sizeof(float)));
+    P.cap_shq = cap;
+    P.shq.ray = (float4 *)P.d_shq_mem;
+    P.shq.id = (uint32_t *)((float *)P.d_shq_mem + 8 * (size_t)cap);
     return 0;
 }
 
@@ -310,17 +328,13 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     };
     hipError_t e;
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return bail("hipSetDevice", e);
-    if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) return bail("hipStreamCreate", e);
-    for (auto &row : ctx->ev)
-        for (auto &ev : row)
-            if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-    for (auto &ev : ctx->ev_misc)
-        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     {
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
         ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    for (auto &ev : ctx->ev_misc)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     FrameGeom &g = ctx->g;
     g.W = cfg->width * cfg->supersampling;
     g.H = cfg->height * cfg->supersampling;
@@ -328,8 +342,39 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     g.n_tiles = g.tiles_x * ((g.H + 7) / 8);
     g.shard_index = cfg->shard_index;
     g.shard_count = sc;
-    uint32_t my_tiles = (uint32_t)((g.n_tiles - g.shard_index + sc - 1) / sc);
+    g.compact_mul = 1;
+    g.compact_add = 0;
+    const uint32_t my_tiles = (uint32_t)((g.n_tiles - g.shard_index + sc - 1) / sc);
     ctx->n0 = my_tiles * 64u;
+    // parts: cfg.parts, else the environment (RT_PARTS), else 2; never more parts than tiles
+    int np = cfg->parts;
+    if (np <= 0) {
+        const char *env = getenv("RT_PARTS");
+        np = env ? atoi(env) : 2;
+    }
+    np = std::max(1, std::min({np, MAX_PARTS, (int)std::max<uint32_t>(my_tiles, 1u)}));
+    ctx->n_parts = np;
+    for (int p = 0; p < np; p++) {
+        Part &P = ctx->parts[p];
+        if ((e = hipStreamCreate(&P.stream)) != hipSuccess) return bail("hipStreamCreate", e);
+        for (auto &row : P.ev)
+            for (auto &ev : row)
+                if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+        for (hipEvent_t *ev : {&P.ev_begin, &P.ev_comp, &P.ev_end})
+            if ((e = hipEventCreate(ev)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipMalloc((void **)&P.d_counts, MAX_LEVELS * sizeof(LevelCounters))) != hipSuccess) return bail("hipMalloc", e);
+        if ((e = hipMemset(P.d_counts, 0, MAX_LEVELS * sizeof(LevelCounters))) != hipSuccess) return bail("hipMemset", e);
+        if ((e = hipHostMalloc((void **)&P.h_counts, MAX_LEVELS * sizeof(LevelCounters))) != hipSuccess) return bail("hipHostMalloc", e);
+        // part p takes every np-th tile of the shard: tiles shard_index + shard_count * (p + np * j)
+        P.g = g;
+        P.g.shard_index = g.shard_index + g.shard_count * p;
+        P.g.shard_count = g.shard_count * np;
+        P.g.compact_mul = np;
+        P.g.compact_add = p;
+        const uint32_t part_tiles = my_tiles > (uint32_t)p ? (my_tiles - (uint32_t)p + (uint32_t)np - 1u) / (uint32_t)np : 0u;
+        P.n0 = part_tiles * 64u;
+    }
+    ctx->stream = ctx->parts[0].stream;
     const size_t npx = (size_t)g.W * g.H;
 #define ALLOC(p, bytes)                                                                    \
     if ((e = hipMalloc((void **)&(p), (bytes))) != hipSuccess) return bail("hipMalloc", e); \
@@ -340,7 +385,6 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     ALLOC(ctx->d_hit, npx * 4);
     ALLOC(ctx->d_compact, std::max<size_t>(ctx->n0, 64) * 4);
     ALLOC(ctx->d_canvas, (size_t)cfg->width * cfg->height * 4);
-    ALLOC(ctx->d_counts, MAX_LEVELS * sizeof(LevelCounters));
     ALLOC(ctx->d_part_sum, TONE_BLOCKS * sizeof(double));
     ALLOC(ctx->d_part_cnt, TONE_BLOCKS * sizeof(unsigned long long));
     ALLOC(ctx->d_tone_out, sizeof(double));
@@ -354,20 +398,27 @@ void rt_destroy(rt_ctx *ctx) {
     if (!ctx) return;
     if (ctx->host_only) { delete ctx; return; }
     (void)hipSetDevice(ctx->cfg.device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();
     void *ptrs[] = {ctx->d_scene, ctx->d_prims, ctx->d_mats, ctx->d_lights, ctx->d_tris, ctx->d_nodes, ctx->d_ltris,
-                    ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_canvas, ctx->d_counts, ctx->d_kdq,
-                    ctx->d_recs, ctx->d_shq_mem, ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt};
+                    ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_canvas,
+                    ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    for (auto &l : ctx->lv)
-        if (l.mem) (void)hipFree(l.mem);
-    for (auto &row : ctx->ev)
-        for (auto &ev : row)
-            if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->ev_misc)
         if (ev) (void)hipEventDestroy(ev);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (Part &P : ctx->parts) {
+        for (void *p : {(void *)P.d_counts, (void *)P.d_kdq, (void *)P.d_recs, P.d_shq_mem})
+            if (p) (void)hipFree(p);
+        if (P.h_counts) (void)hipHostFree(P.h_counts);
+        for (auto &l : P.lv)
+            if (l.mem) (void)hipFree(l.mem);
+        for (auto &row : P.ev)
+            for (auto &ev : row)
+                if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : {P.ev_begin, P.ev_comp, P.ev_end})
+            if (ev) (void)hipEventDestroy(ev);
+        if (P.stream) (void)hipStreamDestroy(P.stream);
+    }
     delete ctx;
 }
 
@@ -477,6 +528,87 @@ int rt_export_kdtree_reference(rt_ctx *ctx, uint32_t *nodes, int32_t *leaves, do
     return 0;
 }
 
+// launches the seven stages of level l of one part and the copy of its counters to the host
+static int launch_level(rt_ctx *ctx, Part &P, int l) {
+    const int D = ctx->cfg.max_depth;
+    const SceneDev &sh = ctx->sh;
+    const bool walk = sh.render_triangles && sh.use_kd;
+    const bool last = (l == D - 1);
+    const uint32_t n = P.n_rays[l];
+    hipStream_t s = P.stream;
+    if (!last) {
+        uint64_t want = std::min<uint64_t>(2ull * n, 0x7fffff00ull);
+        if (ensure_level(ctx, P, l + 1, (uint32_t)want)) return -1;
+    }
+    if (ensure_queues(ctx, P, n, (uint32_t)sh.n_lights)) return -1;
+    if (walk && P.cap_recs == 0 && ensure(ctx, P.d_recs, P.cap_recs, std::max<size_t>((size_t)8 << 20, (size_t)n * 16))) return -1;
+    LevelArgs A{};
+    A.S = ctx->sh;
+    A.cur = P.lv[l].b;
+    if (!last) { A.nxt = P.lv[l + 1].b; A.nxt_cap = P.lv[l + 1].cap; }
+    A.shq = P.shq;
+    A.shq_cap = P.cap_shq;
+    A.kdq = P.d_kdq;
+    A.recs = P.d_recs;
+    A.rec_cap = (uint32_t)std::min<size_t>(P.cap_recs, 0x3fffff00u);
+    A.cnt = P.d_counts + l;
+    A.n_rays = n;
+    A.hit_ids = ctx->d_hit;
+    A.g = P.g;
+    A.level = l;
+    A.last_level = last ? 1 : 0;
+    WalkArgs Wk{ctx->sh, P.lv[l].b, P.shq, P.d_kdq, P.d_recs, P.d_counts + l, P.cap_shq, A.rec_cap};
+    const dim3 grid((n + BLOCK - 1) / BLOCK);
+    // persistent traversal waves: one 64-lane workgroup each (4 KB of LDS for the short stacks)
+    const dim3 walk_grid((unsigned)ctx->n_cus * (unsigned)RT_WALK_WAVES_PER_CU);
+    const dim3 test_grid((unsigned)ctx->n_cus * 32u);   // grid-stride over the records
+    hipEvent_t *ev = P.ev[l];
+    HIPCK(hipEventRecord(ev[0], s));
+    hipLaunchKernelGGL(k_gen_prims, grid, dim3(BLOCK), 0, s, A);
+    HIPCK(hipEventRecord(ev[1], s));
+    if (walk) hipLaunchKernelGGL(k_kd_walk<false>, walk_grid, dim3(WAVE), 0, s, Wk);
+    HIPCK(hipEventRecord(ev[2], s));
+    if (walk) hipLaunchKernelGGL(k_tri_test<false>, test_grid, dim3(256), 0, s, Wk);
+    HIPCK(hipEventRecord(ev[3], s));
+    hipLaunchKernelGGL(k_shade_a, grid, dim3(BLOCK), 0, s, A);
+    HIPCK(hipEventRecord(ev[4], s));
+    if (walk) hipLaunchKernelGGL(k_kd_walk<true>, walk_grid, dim3(WAVE), 0, s, Wk);
+    HIPCK(hipEventRecord(ev[5], s));
+    if (walk) hipLaunchKernelGGL(k_tri_test<true>, test_grid, dim3(256), 0, s, Wk);
+    HIPCK(hipEventRecord(ev[6], s));
+    hipLaunchKernelGGL(k_shade_b, grid, dim3(BLOCK), 0, s, A);
+    HIPCK(hipGetLastError());
+    HIPCK(hipEventRecord(ev[7], s));
+    HIPCK(hipMemcpyAsync(P.h_counts + l, P.d_counts + l, sizeof(LevelCounters), hipMemcpyDeviceToHost, s));
+    P.pending = l;
+    return 0;
+}
+
+// waits for the pending level of a part. One host round trip per level and part: the number of children sizes
+// the next level, and a walk that ran out of record space wrote nothing past the capacity, so the level is repeated
+// with a larger buffer. Returns 1 when the level has to be launched again, 0 when it is complete.
+static int collect_level(rt_ctx *ctx, Part &P) {
+    const int l = P.pending;
+    const int D = ctx->cfg.max_depth;
+    const bool walk = ctx->sh.render_triangles && ctx->sh.use_kd;
+    HIPCK(hipStreamSynchronize(P.stream));
+    P.pending = -1;
+    const LevelCounters &hc = P.h_counts[l];
+    const size_t need = std::max<size_t>(hc.rec_count[0], hc.rec_count[1]);
+    const size_t rec_cap = std::min<size_t>(P.cap_recs, 0x3fffff00u);
+    if (walk && need > rec_cap) {
+        if (P.attempt >= 3 || need > 0x3fffff00u) return fail(ctx, "rt_trace: triangle record buffer cannot hold one level");
+        if (ensure(ctx, P.d_recs, P.cap_recs, need + need / 4)) return -1;
+        HIPCK(hipMemsetAsync(P.d_counts + l, 0, sizeof(LevelCounters), P.stream));
+        P.attempt++;
+        return 1;
+    }
+    P.attempt = 0;
+    if (l < D - 1) P.n_rays[l + 1] = std::min(hc.next_count, P.lv[l + 1].cap);
+    P.levels_run = l + 1;
+    return 0;
+}
+
 int rt_trace(rt_ctx *ctx) {
     if (!ctx) return -1;
     if (ctx->host_only) return fail(ctx, "rt_trace: host-only context (created with device = -1)");
@@ -484,93 +616,51 @@ int rt_trace(rt_ctx *ctx) {
     if (ctx->scene_dirty && upload_scene(ctx)) return -1;
     const int D = ctx->cfg.max_depth;
     const SceneDev &sh = ctx->sh;
-    const bool walk = sh.render_triangles && sh.use_kd;
-    hipStream_t s = ctx->stream;
-    HIPCK(hipMemsetAsync(ctx->d_counts, 0, MAX_LEVELS * sizeof(LevelCounters), s));
-    memset(ctx->n_rays, 0, sizeof ctx->n_rays);
-    ctx->n_rays[0] = ctx->n0;
-    if (ensure_level(ctx, 0, ctx->n0)) return -1;
-    hipEvent_t ev_begin = ctx->ev_misc[0], ev_comp = ctx->ev_misc[1], ev_end = ctx->ev_misc[2];
-    HIPCK(hipEventRecord(ev_begin, s));
-    // persistent traversal waves: one 64-lane workgroup each (4 KB of LDS for the short stacks)
-    const dim3 walk_grid((unsigned)ctx->n_cus * (unsigned)RT_WALK_WAVES_PER_CU);
-    const dim3 test_grid((unsigned)ctx->n_cus * 32u);   // grid-stride over the records
-    int levels_run = 0;
-    for (int l = 0; l < D; l++) {
-        const uint32_t n = ctx->n_rays[l];
-        if (n == 0) break;
-        const bool last = (l == D - 1);
-        if (!last) {
-            uint64_t want = std::min<uint64_t>(2ull * n, 0x7fffff00ull);
-            if (ensure_level(ctx, l + 1, (uint32_t)want)) return -1;
-        }
-        if (ensure_queues(ctx, n, (uint32_t)sh.n_lights)) return -1;
-        if (walk && ctx->cap_recs == 0 && ensure(ctx, ctx->d_recs, ctx->cap_recs, std::max<size_t>((size_t)16 << 20, (size_t)n * 16))) return -1;
-        for (int attempt = 0;; attempt++) {
-            LevelArgs A{};
-            A.S = ctx->sh;
-            A.cur = ctx->lv[l].b;
-            if (!last) { A.nxt = ctx->lv[l + 1].b; A.nxt_cap = ctx->lv[l + 1].cap; }
-            A.shq = ctx->shq;
-            A.shq_cap = ctx->cap_shq;
-            A.kdq = ctx->d_kdq;
-            A.recs = ctx->d_recs;
-            A.rec_cap = (uint32_t)std::min<size_t>(ctx->cap_recs, 0x3fffff00u);
-            A.cnt = ctx->d_counts + l;
-            A.n_rays = n;
-            A.hit_ids = ctx->d_hit;
-            A.g = ctx->g;
-            A.level = l;
-            A.last_level = last ? 1 : 0;
-            WalkArgs Wk{ctx->sh, ctx->lv[l].b, ctx->shq, ctx->d_kdq, ctx->d_recs, ctx->d_counts + l, ctx->cap_shq, A.rec_cap};
-            const dim3 grid((n + BLOCK - 1) / BLOCK);
-            hipEvent_t *ev = ctx->ev[l];
-            HIPCK(hipEventRecord(ev[0], s));
-            hipLaunchKernelGGL(k_gen_prims, grid, dim3(BLOCK), 0, s, A);
-            HIPCK(hipEventRecord(ev[1], s));
-            if (walk) hipLaunchKernelGGL(k_kd_walk<false>, walk_grid, dim3(WAVE), 0, s, Wk);
-            HIPCK(hipEventRecord(ev[2], s));
-            if (walk) hipLaunchKernelGGL(k_tri_test<false>, test_grid, dim3(256), 0, s, Wk);
-            HIPCK(hipEventRecord(ev[3], s));
-            hipLaunchKernelGGL(k_shade_a, grid, dim3(BLOCK), 0, s, A);
-            HIPCK(hipEventRecord(ev[4], s));
-            if (walk) hipLaunchKernelGGL(k_kd_walk<true>, walk_grid, dim3(WAVE), 0, s, Wk);
-            HIPCK(hipEventRecord(ev[5], s));
-            if (walk) hipLaunchKernelGGL(k_tri_test<true>, test_grid, dim3(256), 0, s, Wk);
-            HIPCK(hipEventRecord(ev[6], s));
-            hipLaunchKernelGGL(k_shade_b, grid, dim3(BLOCK), 0, s, A);
-            HIPCK(hipGetLastError());
-            HIPCK(hipEventRecord(ev[7], s));
-            // one host round trip per level: the number of children (sizes the next level) and the record
-            // counts (a walk that ran out of record space wrote nothing past the capacity: repeat the level)
-            LevelCounters hc;
-            HIPCK(hipMemcpyAsync(&hc, ctx->d_counts + l, sizeof hc, hipMemcpyDeviceToHost, s));
-            HIPCK(hipStreamSynchronize(s));
-            const size_t need = std::max<size_t>(hc.rec_count[0], hc.rec_count[1]);
-            if (walk && need > A.rec_cap) {
-                if (attempt >= 3 || need > 0x3fffff00u) return fail(ctx, "rt_trace: triangle record buffer cannot hold one level");
-                if (ensure(ctx, ctx->d_recs, ctx->cap_recs, need + need / 4)) return -1;
-                HIPCK(hipMemsetAsync(ctx->d_counts + l, 0, sizeof(LevelCounters), s));
-                continue;
+    const int NP = ctx->n_parts;
+    // level 0 of every part goes out first; from then on a part's next level is launched as soon as its
+    // counters are back, while the other parts keep the GPU busy
+    for (int p = 0; p < NP; p++) {
+        Part &P = ctx->parts[p];
+        P.levels_run = 0;
+        P.pending = -1;
+        P.attempt = 0;
+        memset(P.n_rays, 0, sizeof P.n_rays);
+        P.n_rays[0] = P.n0;
+        HIPCK(hipMemsetAsync(P.d_counts, 0, MAX_LEVELS * sizeof(LevelCounters), P.stream));
+        HIPCK(hipEventRecord(P.ev_begin, P.stream));
+        if (P.n0 == 0) continue;
+        if (ensure_level(ctx, P, 0, P.n0)) return -1;
+        if (launch_level(ctx, P, 0)) return -1;
+    }
+    for (bool busy = true; busy;) {
+        busy = false;
+        for (int p = 0; p < NP; p++) {
+            Part &P = ctx->parts[p];
+            if (P.pending < 0) continue;
+            const int l = P.pending;
+            const int again = collect_level(ctx, P);
+            if (again < 0) return -1;
+            int next = again ? l : l + 1;
+            if (next < D && P.n_rays[next] > 0) {
+                if (launch_level(ctx, P, next)) return -1;
+                busy = true;
             }
-            if (!last) ctx->n_rays[l + 1] = std::min(hc.next_count, ctx->lv[l + 1].cap);
-            break;
         }
-        levels_run = l + 1;
     }
-    HIPCK(hipEventRecord(ev_comp, s));
-    for (int l = levels_run - 2; l >= 0; l--) {
-        if (ctx->n_rays[l + 1] == 0) continue;
-        hipLaunchKernelGGL(k_composite, dim3((ctx->n_rays[l] + 255) / 256), dim3(256), 0, s, ctx->lv[l].b, ctx->lv[l + 1].b,
-                           ctx->n_rays[l]);
+    for (int p = 0; p < NP; p++) {
+        Part &P = ctx->parts[p];
+        hipStream_t s = P.stream;
+        HIPCK(hipEventRecord(P.ev_comp, s));
+        for (int l = P.levels_run - 2; l >= 0; l--) {
+            if (P.n_rays[l + 1] == 0) continue;
+            hipLaunchKernelGGL(k_composite, dim3((P.n_rays[l] + 255) / 256), dim3(256), 0, s, P.lv[l].b, P.lv[l + 1].b, P.n_rays[l]);
+        }
+        if (P.n0) hipLaunchKernelGGL(k_resolve, dim3((P.n0 + 255) / 256), dim3(256), 0, s, P.lv[0].b, P.n0, P.g, ctx->d_fb,
+                                     ctx->d_rgba, ctx->d_compact);
+        HIPCK(hipGetLastError());
+        HIPCK(hipEventRecord(P.ev_end, s));
     }
-    hipLaunchKernelGGL(k_resolve, dim3((ctx->n0 + 255) / 256), dim3(256), 0, s, ctx->lv[0].b, ctx->n0, ctx->g, ctx->d_fb,
-                       ctx->d_rgba, ctx->d_compact);
-    HIPCK(hipGetLastError());
-    HIPCK(hipEventRecord(ev_end, s));
-    LevelCounters hc[MAX_LEVELS];
-    HIPCK(hipMemcpyAsync(hc, ctx->d_counts, sizeof hc, hipMemcpyDeviceToHost, s));
-    HIPCK(hipStreamSynchronize(s));
+    for (int p = 0; p < NP; p++) HIPCK(hipStreamSynchronize(ctx->parts[p].stream));
 
     rt_stats &st = ctx->st;
     const double keep_build = st.kd_build_ms, keep_upload = st.kd_upload_ms, keep_tone = st.tone_ms;
@@ -586,32 +676,44 @@ int rt_trace(rt_ctx *ctx) {
         st.pixels = px;
         st.rays_per_level[0] = px;
     }
-    for (int l = 1; l < levels_run; l++) st.rays_per_level[l] = ctx->n_rays[l];
-    for (int l = 0; l < levels_run; l++) {
-        st.rays_total += st.rays_per_level[l];
-        st.shadow_rays += (uint64_t)hc[l].shaded * (uint64_t)sh.n_lights;
-        st.kd_closest_rays += hc[l].kdq_count;
-        st.kd_shadow_rays += hc[l].shq_count;
-        st.tri_records[0] += hc[l].rec_count[0];
-        st.tri_records[1] += hc[l].rec_count[1];
+    // kernel times are summed over the parts; with more than one part the kernels of different parts share the
+    // GPU, so these are occupancy-weighted durations, not exclusive ones
+    for (int p = 0; p < NP; p++) {
+        const Part &P = ctx->parts[p];
+        for (int l = 1; l < P.levels_run; l++) st.rays_per_level[l] += P.n_rays[l];
+        for (int l = 0; l < P.levels_run; l++) {
+            const LevelCounters &hc = P.h_counts[l];
+            st.shadow_rays += (uint64_t)hc.shaded * (uint64_t)sh.n_lights;
+            st.kd_closest_rays += hc.kdq_count;
+            st.kd_shadow_rays += hc.shq_count;
+            st.tri_records[0] += hc.rec_count[0];
+            st.tri_records[1] += hc.rec_count[1];
 #ifdef RT_WALK_STATS
-        fprintf(stderr, "walk stats level %d: closest iters %llu visits %llu | shadow iters %llu visits %llu\n", l, hc[l].walk_iters[0],
-                hc[l].walk_visits[0], hc[l].walk_iters[1], hc[l].walk_visits[1]);
+            fprintf(stderr, "walk stats part %d level %d: closest iters %llu visits %llu | shadow iters %llu visits %llu\n", p, l,
+                    hc.walk_iters[0], hc.walk_visits[0], hc.walk_iters[1], hc.walk_visits[1]);
+            for (int k = 0; k < 2; k++) {
+                const double span = (double)(hc.walk_t1[k] - ~hc.walk_t0[k]) * 0.01;   // microseconds
+                const double mean = (double)hc.walk_tsum[k] * 0.01 / ((double)ctx->n_cus * RT_WALK_WAVES_PER_CU);
+                fprintf(stderr, "    %s walk: first wave start to last wave end %.1f us, mean wave lifetime %.1f us (%.0f%% of the span)\n",
+                        k ? "shadow " : "closest", span, mean, span > 0 ? 100.0 * mean / span : 0.0);
+            }
 #endif
-        float ms = 0;
-        for (int k = 0; k < N_STAGES; k++) {
-            HIPCK(hipEventElapsedTime(&ms, ctx->ev[l][k], ctx->ev[l][k + 1]));
-            st.level_stage_ms[l][k] = ms;
-            st.stage_ms[k] += ms;
+            float ms = 0;
+            for (int k = 0; k < N_STAGES; k++) {
+                HIPCK(hipEventElapsedTime(&ms, P.ev[l][k], P.ev[l][k + 1]));
+                st.level_stage_ms[l][k] += ms;
+                st.stage_ms[k] += ms;
+            }
+            HIPCK(hipEventElapsedTime(&ms, P.ev[l][0], P.ev[l][N_STAGES]));
+            st.level_kernel_ms[l] += ms;
         }
-        HIPCK(hipEventElapsedTime(&ms, ctx->ev[l][0], ctx->ev[l][N_STAGES]));
-        st.level_kernel_ms[l] = ms;
+        float ms = 0;
+        HIPCK(hipEventElapsedTime(&ms, ctx->parts[0].ev_begin, P.ev_end));
+        st.trace_ms = std::max(st.trace_ms, (double)ms);
+        HIPCK(hipEventElapsedTime(&ms, P.ev_comp, P.ev_end));
+        st.composite_ms += ms;
     }
-    float ms = 0;
-    HIPCK(hipEventElapsedTime(&ms, ev_begin, ev_end));
-    st.trace_ms = ms;
-    HIPCK(hipEventElapsedTime(&ms, ev_comp, ev_end));
-    st.composite_ms = ms;
+    for (int l = 0; l < MAX_LEVELS; l++) st.rays_total += st.rays_per_level[l];
     ctx->traced = true;
     return 0;
 }
@@ -653,7 +755,7 @@ int rt_tone_partial(rt_ctx *ctx, double *sum_log, uint64_t *count) {
     if (!ctx->traced) return fail(ctx, "rt_tone_partial: nothing traced yet");
     HIPCK(hipSetDevice(ctx->cfg.device));
     hipStream_t s = ctx->stream;
-    hipEvent_t e0 = ctx->ev_misc[0], e1 = ctx->ev_misc[3];
+    hipEvent_t e0 = ctx->ev_misc[0], e1 = ctx->ev_misc[1];
     HIPCK(hipEventRecord(e0, s));
     int blocks = (int)std::min<uint32_t>((ctx->n0 + 255) / 256, TONE_BLOCKS);
     if (blocks < 1) blocks = 1;

@@ -55,7 +55,9 @@ constexpr int SHADOWQ_ARRAYS = 9;
 constexpr int MAX_LIGHTS = 32;
 
 struct FrameGeom {
-    int32_t W, H, tiles_x, n_tiles, shard_index, shard_count;
+    int32_t W, H, tiles_x, n_tiles;
+    int32_t shard_index, shard_count;   // level-0 entry tid belongs to tile shard_index + (tid >> 6) * shard_count
+    int32_t compact_mul, compact_add;   // and to tile (tid >> 6) * compact_mul + compact_add of the shard's compact buffer
 };
 
 // device counters of one level; every counter sits in its own 128-byte line so that atomics on different
@@ -68,7 +70,7 @@ struct LevelCounters {
     uint32_t next_count, pad4[31];
     uint32_t shaded, pad5[31];
     uint32_t rec_count[2], pad6[30];      // triangle records written by the closest / shadow walk
-    unsigned long long walk_iters[2], walk_visits[2], pad7[12];   // RT_WALK_STATS builds only: wave iterations, lane node visits
+    unsigned long long walk_iters[2], walk_visits[2], walk_t0[2], walk_t1[2], walk_tsum[2], pad7[6];   // RT_WALK_STATS builds only: wave iterations, lane node visits, first start / last end / summed lifetime of the waves (100 MHz ticks)
 };
 
 constexpr int BLOCK = 1024;   // lanes per workgroup of the one-lane-per-ray kernels
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
     uint32_t rec_pos = 0, rec_end = 0;       // wave-uniform: record slots reserved in A.recs
 #ifdef RT_WALK_STATS
     unsigned long long st_iters = 0, st_visits = 0;
+    const unsigned long long st_begin = wall_clock64();
 #endif
 
     for (;;) {
@@ -348,7 +351,18 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
         // internal node: classify the children and pick the side(s) the ray interval touches
         const uint32_t a = (info >> 28) & 3u;
         const float o = a == 0u ? ox : (a == 1u ? oy : oz), d = a == 0u ? dx : (a == 1u ? dy : dz);
+#ifdef RT_DBG_APPROX_DIV
+        const float t = (split - o) * __builtin_amdgcn_rcpf(d);   // timing experiment only: not the reference's arithmetic
+#else
         const float t = (split - o) / d;
+#endif
+#ifdef RT_DBG_EXTRA_VALU
+        {   // timing experiment only: dead full-rate vector instructions
+            uint32_t dead = info;
+            for (int xd = 0; xd < RT_DBG_EXTRA_VALU; xd++) asm volatile("v_add_u32 %0, %0, %0" : "+v"(dead));
+            asm volatile("" : : "v"(dead));
+        }
+#endif
         const uint32_t child = info & 0x0fffffffu;
         const uint32_t neg = d <= 0.0f ? 1u : 0u;
         const uint32_t nearc = child + neg, farc = child + 1u - neg;
@@ -401,6 +415,10 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
     if (lane == 0) {
         atomicAdd(&A.cnt->walk_iters[ANY ? 1 : 0], st_iters);
         atomicAdd(&A.cnt->walk_visits[ANY ? 1 : 0], st_visits);
+        const unsigned long long st_end = wall_clock64();
+        atomicMax(&A.cnt->walk_t0[ANY ? 1 : 0], ~st_begin);   // counters start at zero: the minimum is kept as the maximum of the complement
+        atomicMax(&A.cnt->walk_t1[ANY ? 1 : 0], st_end);
+        atomicAdd(&A.cnt->walk_tsum[ANY ? 1 : 0], st_end - st_begin);
     }
 #endif
 #undef RANK_IN
@@ -722,13 +740,14 @@ __global__ __launch_bounds__(256) void k_resolve(LevelBuf l0, uint32_t n, FrameG
     uint32_t tid = blockIdx.x * 256 + threadIdx.x;
     if (tid >= n) return;
     int x, y;
-    if (!pixel_of(g, tid, x, y)) { compact[tid] = 0u; return; }
+    const size_t ci = ((size_t)(tid >> 6) * (uint32_t)g.compact_mul + (uint32_t)g.compact_add) * 64u + (tid & 63u);
+    if (!pixel_of(g, tid, x, y)) { compact[ci] = 0u; return; }
     float r = l0.cr[tid], gg = l0.cg[tid], b = l0.cb[tid];
     size_t p = (size_t)y * g.W + x;
     fb[3 * p] = r; fb[3 * p + 1] = gg; fb[3 * p + 2] = b;
     uint32_t v = quant8(r) | (quant8(gg) << 8) | (quant8(b) << 16) | 0xff000000u;
     rgba[p] = v;
-    compact[tid] = v;
+    compact[ci] = v;
 }
 
 // sum over this shard of log(EPSILON + L), L = 0.27 r + 0.67 g + 0.07 b with r = byte * L_MAX / 256

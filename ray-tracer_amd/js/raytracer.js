@@ -28,6 +28,7 @@ function packConfig(G, device, shardIndex, shardCount) {
     dv.setInt32(64, shardIndex, true);
     dv.setInt32(68, shardCount, true);
     dv.setInt32(72, device, true);
+    dv.setInt32(76, G.PARTS | 0, true);   // concurrent slices of the shard, 0 = library default
     return buf;
 }
 
