@@ -64,7 +64,7 @@ typedef struct rt_config {
                                     export work, every entry point that needs a GPU fails) */
     /* the shard is traced as `parts` independent slices of its tiles on separate HIP streams, so that the
      * end of one slice's kernels (a few long rays) overlaps the other slices' work. 0 = library default
-     * (environment RT_PARTS, else 2); 1 = one stream. The image does not depend on it. No counterpart in the reference. */
+     * (environment RT_PARTS, else 1); 1 = one stream. The image does not depend on it. No counterpart in the reference. */
     int32_t parts;
 } rt_config;
 

@@ -346,11 +346,12 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     g.compact_add = 0;
     const uint32_t my_tiles = (uint32_t)((g.n_tiles - g.shard_index + sc - 1) / sc);
     ctx->n0 = my_tiles * 64u;
-    // parts: cfg.parts, else the environment (RT_PARTS), else 2; never more parts than tiles
+    // parts: cfg.parts, else the environment (RT_PARTS), else 1 (measured: with the current kernels a second part
+    // neither helps nor hurts much - the walks are throughput-bound, not tail-bound); never more parts than tiles
     int np = cfg->parts;
     if (np <= 0) {
         const char *env = getenv("RT_PARTS");
-        np = env ? atoi(env) : 2;
+        np = env ? atoi(env) : 1;
     }
     np = std::max(1, std::min({np, MAX_PARTS, (int)std::max<uint32_t>(my_tiles, 1u)}));
     ctx->n_parts = np;

@@ -173,3 +173,18 @@ def test_full_size_config3_properties_and_sampled_parity():
     wl, ws = o.tone(a8)
     assert abs(Lbar - wl) <= 1e-8 * wl and abs(sf - ws) <= 1e-8 * ws      # 8.3 M sequential adds in the reference
     assert np.float32(sf) == np.float32(ws)                                 # what the present shader receives
+
+
+def test_parts_do_not_change_the_image():
+    """rt_config.parts traces the shard as concurrent slices on separate streams; every output must be the same."""
+    outs = []
+    for parts in (1, 3):
+        flat = make_flat("bun_zipper_res4.ply", 331, 203, depth=4, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9), parts=parts)
+        rt = abi.RayTracerHIP(flat.cfg)
+        rt.setScene(flat)
+        rt.trace()
+        st = rt.stats()
+        outs.append((sha(rt.readFloat()), sha(rt.readRGBA8()), sha(rt.readHitIds()), rt.tone(), sha(rt.present()),
+                     st.rays_total, st.shadow_rays, list(st.rays_per_level)))
+        rt.close()
+    assert outs[0] == outs[1]
