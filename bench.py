@@ -151,11 +151,12 @@ def main():
         "pcie_inclusive": None if pcie_ms is None else {"ms_per_step": pcie_ms, "value": rays / (pcie_ms * 1e-3) / 1e6,
                                                         "note": "step + rt_read_rgba8 of the 3840x2160 RGBA8 target into pageable host memory"},
         "trace_only_ms": trace_ms / K, "composite_ms": comp_ms / K, "tone_ms": tone_ms / K,
-        "level_kernel_ms": [round(float(x), 4) for x in lvl_ms[:args.depth]],
-        "stage_names": ["k_gen_prims", "k_kd_walk<closest>", "k_tri_test<closest>", "k_shade_a", "k_kd_walk<shadow>", "k_tri_test<shadow>", "k_shade_b"],
+        "step_kernel_ms": [round(float(x), 4) for x in lvl_ms[:args.depth + 1]],
+        "stage_names": ["k_gen_prims", "k_kd_walk", "k_tri_test", "k_shade_b", "k_shade_a"],
+        "pipeline_step": "step k = k_gen_prims(level k), k_kd_walk + k_tri_test (closest-hit rays of level k with the shadow rays of level k-1), k_shade_b(level k-1), k_shade_a(level k)",
         "tri_records": [int(x) for x in st.tri_records],
-        "level_stage_ms": [[round(float(x), 4) for x in row] for row in stage_ms[:args.depth]],
-        "stage_ms": [round(float(x), 4) for x in stage_ms.sum(axis=0)],
+        "step_stage_ms": [[round(float(x), 4) for x in row[:5]] for row in stage_ms[:args.depth + 1]],
+        "stage_ms": [round(float(x), 4) for x in stage_ms.sum(axis=0)[:5]],
         "kd_closest_rays": int(st.kd_closest_rays), "kd_shadow_rays": int(st.kd_shadow_rays),
         "kd_build_ms": st.kd_build_ms, "kd_upload_ms": st.kd_upload_ms, "scene_setup_s": setup_s,
     }
@@ -181,27 +182,29 @@ def main():
         # stream around every launch (rt_stats.level_stage_ms), averaged over the launches of the timed steps.
         scale = float(args.cpu_step ** 2) / world
         D = args.depth
-        names = out["stage_names"]
-        per_stage_bytes = np.zeros(7)
-        per_stage_flops = np.zeros(7)
+        n_steps = D + 1
+        # per pipeline stage: reference-algorithm bytes and flops of everything that stage does in one frame
+        per_stage_bytes = np.zeros(5)
+        per_stage_flops = np.zeros(5)
         for lv in range(D):
-            per_stage_bytes += np.array([128.0 * cn.prim_tests[lv], 8.0 * cn.kd_steps[lv] + 16.0 * cn.kd_leaf_visits[lv], 48.0 * cn.kd_tri_tests[lv],
-                                         128.0 * cn.sh_prim_tests[lv], 8.0 * cn.sh_steps[lv] + 16.0 * cn.sh_leaf_visits[lv], 48.0 * cn.sh_tri_tests[lv], 0.0])
-            per_stage_flops += np.array([60.0 * cn.prim_tests[lv], 14.0 * cn.kd_steps[lv], 45.0 * cn.kd_tri_tests[lv],
-                                         60.0 * cn.sh_prim_tests[lv], 14.0 * cn.sh_steps[lv], 45.0 * cn.sh_tri_tests[lv], 0.0])
+            per_stage_bytes += np.array([128.0 * cn.prim_tests[lv],
+                                         8.0 * (cn.kd_steps[lv] + cn.sh_steps[lv]) + 16.0 * (cn.kd_leaf_visits[lv] + cn.sh_leaf_visits[lv]),
+                                         48.0 * (cn.kd_tri_tests[lv] + cn.sh_tri_tests[lv]), 0.0, 128.0 * cn.sh_prim_tests[lv]])
+            per_stage_flops += np.array([60.0 * cn.prim_tests[lv], 14.0 * (cn.kd_steps[lv] + cn.sh_steps[lv]),
+                                         45.0 * (cn.kd_tri_tests[lv] + cn.sh_tri_tests[lv]), 0.0, 60.0 * cn.sh_prim_tests[lv]])
         per_stage_bytes *= scale
         per_stage_flops *= scale
-        tot_ms = stage_ms[:D].sum(axis=0)
-        launches = np.array([(stage_ms[:D, k] > 0).sum() for k in range(7)], dtype=float)
+        tot_ms = stage_ms[:n_steps, :5].sum(axis=0)
+        launches = np.array([(stage_ms[:n_steps, k] > 0).sum() for k in range(5)], dtype=float)
         dom = int(np.argmax(tot_ms))
         digest = {}
         dpath = os.path.join(ROOT, "profiles", "r01_pmc_digest.json")
         if os.path.exists(dpath):
             with open(dpath) as f:
                 digest = json.load(f)
-        prof_name = {1: "k_kd_walk<false>", 2: "k_tri_test<false>", 4: "k_kd_walk<true>", 5: "k_tri_test<true>", 0: "k_gen_prims", 3: "k_shade_a", 6: "k_shade_b"}
+        prof_name = dict(enumerate(out["stage_names"]))
         table = []
-        for k in range(7):
+        for k in range(5):
             if launches[k] == 0:
                 continue
             dur_s = tot_ms[k] / launches[k] * 1e-3
@@ -217,7 +220,7 @@ def main():
             "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
             "launches_per_frame": d["launches_per_frame"],
             "valu_tflops": d["valu_tflops"], "valu_frac": d["valu_tflops"] / FP32_PEAK_TFLOPS,
-            "note": "algorithmic bytes = the reference restart traversal's fetches for the same rays (8 B per descent step, 16 B per leaf visit), counted by the instrumented oracle on the sample and scaled to the frame; the scene (about 7 MB) stays in L2 / Infinity Cache, so this walk is bound by dependent-gather latency and VALU/SALU issue, not by HBM or MFMA; `traffic` is HBM bytes per launch from the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE), mostly the ray queue read and the leaf records written",
+            "note": "one k_kd_walk launch per pipeline step walks the closest-hit rays of a ray-tree level together with the shadow rays of the previous one; algorithmic bytes = the reference restart traversal's fetches for the same rays (8 B per descent step, 16 B per leaf visit), counted by the instrumented oracle over the same frame; the scene (about 20 MB) stays in L2 / Infinity Cache, so this walk is bound by dependent-gather latency and instruction issue, not by HBM or MFMA; `traffic` is HBM bytes per launch from the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE), mostly the leaf records written",
         }
         out["kernels"] = table
         out["algorithmic_frame"] = {k: v * scale * world for k, v in cn.algorithmic(None).items()}

@@ -105,11 +105,13 @@ typedef struct rt_stats {
     uint64_t rays_per_level[8]; /* the same, split by ray-tree level */
     uint64_t shadow_rays;       /* lights x shaded nodes */
     uint64_t pixels;            /* pixels of this shard (supersampled resolution) */
-    double   trace_ms;          /* device time of the whole trace (all levels + composite) */
-    double   level_kernel_ms[8];/* device time of one level (all seven stages) */
-    double   level_stage_ms[8][7]; /* per level: analytic closest hit, k-d walk (closest), triangle tests (closest),
-                                      shadow setup, k-d walk (shadow), triangle tests (shadow), shading + spawn */
-    double   stage_ms[7];       /* the same, summed over levels */
+    double   trace_ms;          /* device time of the whole trace (all steps + composite) */
+    /* A frame of depth D runs as D+1 pipeline steps. Step k: analytic closest hit of level k, k-d walk and
+     * triangle tests (closest-hit rays of level k together with the shadow rays of level k-1), shading of
+     * level k-1, hit resolution + children + shadow-ray set-up of level k. Step 8 (depth 8 only) is not itemised. */
+    double   level_kernel_ms[8];/* device time of one step (all five stages) */
+    double   level_stage_ms[8][7]; /* per step, columns 0..4: k_gen_prims, k_kd_walk, k_tri_test, k_shade_b, k_shade_a; 5..6 unused */
+    double   stage_ms[7];       /* the same, summed over all steps */
     uint64_t tri_records[2];    /* (ray, triangle) records listed by the closest / shadow walks */
     uint64_t kd_closest_rays;   /* rays that walked the k-d tree for a closest hit */
     uint64_t kd_shadow_rays;    /* shadow rays that walked the k-d tree */

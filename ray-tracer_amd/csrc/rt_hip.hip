@@ -22,7 +22,11 @@ namespace {
 
 thread_local std::string g_create_error;
 
-constexpr int N_STAGES = 7;   // k_gen_prims, k_kd_walk<closest>, k_tri_test<closest>, k_shade_a, k_kd_walk<any>, k_tri_test<any>, k_shade_b
+// Pipeline step k of a frame: k_gen_prims(level k), k_kd_walk + k_tri_test (closest-hit rays of level k together with
+// the shadow rays of level k-1), k_shade_b(level k-1), k_shade_a(level k). A frame of depth D takes D+1 steps; the
+// last one only finishes the shadow rays of the last level.
+constexpr int N_STAGES = 5;
+constexpr int MAX_STEPS = MAX_LEVELS + 1;
 
 // ------------------------------------------------------------------------------------------------
 struct Level {
@@ -38,23 +42,24 @@ constexpr int MAX_PARTS = 8;
 // drain (a persistent kernel ends only when its slowest ray does), the other parts' kernels fill the machine.
 struct Part {
     hipStream_t stream = nullptr;
-    hipEvent_t ev[MAX_LEVELS][N_STAGES + 1]{};   // stage boundaries of every level
+    hipEvent_t ev[MAX_STEPS][N_STAGES + 1]{};    // stage boundaries of every step
     hipEvent_t ev_begin = nullptr, ev_comp = nullptr, ev_end = nullptr;
     Level lv[MAX_LEVELS];
     LevelCounters *d_counts = nullptr;           // one block of counters per level
     LevelCounters *h_counts = nullptr;           // pinned host copy
     uint4 *d_kdq = nullptr;                      // closest-hit traversal queue, reused by every level
     size_t cap_kdq = 0;
-    void *d_shq_mem = nullptr;                   // shadow traversal queue, reused by every level
-    ShadowQ shq{};
-    uint32_t cap_shq = 0;
-    uint2 *d_recs = nullptr;                     // triangle records of the walk in flight, reused by every level
-    size_t cap_recs = 0;
+    void *d_shq_mem[2] = {nullptr, nullptr};     // shadow traversal queues: level l uses queue l & 1 (the queue of
+    ShadowQ shq[2]{};                            // level l-1 is still being walked while level l fills its own)
+    uint32_t cap_shq[2] = {0, 0};
+    uint2 *d_recs[2] = {nullptr, nullptr};       // leaf records of the closest-hit walk / of the shadow walk in flight
+    size_t cap_recs[2] = {0, 0};
+    uint64_t rec_total[2] = {0, 0};              // records written this frame (statistics)
     uint32_t n_rays[MAX_LEVELS]{};
     FrameGeom g{};
     uint32_t n0 = 0;                             // level-0 entries = tiles of this part * 64
     int levels_run = 0;
-    int pending = -1;                            // level launched and not yet collected, -1 = none
+    int pending = -1;                            // step launched and not yet collected, -1 = none
     int attempt = 0;
 };
 
@@ -154,18 +159,19 @@ int ensure_level(rt_ctx *ctx, Part &P, int l, uint32_t cap) {
 }
 
 // traversal queues are shared by all levels: sized for the largest level seen so far
-int ensure_queues(rt_ctx *ctx, Part &P, uint32_t n_rays, uint32_t n_lights) {
+int ensure_queues(rt_ctx *ctx, Part &P, int level, uint32_t n_rays, uint32_t n_lights) {
     if (ensure(ctx, P.d_kdq, P.cap_kdq, n_rays)) return -1;
+    const int q = level & 1;
     uint64_t want = (uint64_t)n_rays * std::max<uint32_t>(n_lights, 1);
     if (want > 0x7fffff00ull) return fail(ctx, "shadow queue too large");
-    if (P.d_shq_mem && P.cap_shq >= want) return 0;
-    if (P.d_shq_mem) HIPCK(hipFree(P.d_shq_mem));
-    P.d_shq_mem = nullptr;
+    if (P.d_shq_mem[q] && P.cap_shq[q] >= want) return 0;
+    if (P.d_shq_mem[q]) HIPCK(hipFree(P.d_shq_mem[q]));
+    P.d_shq_mem[q] = nullptr;
     uint32_t cap = std::max<uint32_t>(((uint32_t)want + 255u) & ~255u, 256u);
-    HIPCK(hipMalloc(&P.d_shq_mem, (size_t)cap * SHADOWQ_ARRAYS * sizeof(float)));
-    P.cap_shq = cap;
-    P.shq.ray = (float4 *)P.d_shq_mem;
-    P.shq.id = (uint32_t *)((float *)P.d_shq_mem + 8 * (size_t)cap);
+    HIPCK(hipMalloc(&P.d_shq_mem[q], (size_t)cap * SHADOWQ_ARRAYS * sizeof(float)));
+    P.cap_shq[q] = cap;
+    P.shq[q].ray = (float4 *)P.d_shq_mem[q];
+    P.shq[q].id = (uint32_t *)((float *)P.d_shq_mem[q] + 8 * (size_t)cap);
     return 0;
 }
 
@@ -408,7 +414,7 @@ void rt_destroy(rt_ctx *ctx) {
     for (auto &ev : ctx->ev_misc)
         if (ev) (void)hipEventDestroy(ev);
     for (Part &P : ctx->parts) {
-        for (void *p : {(void *)P.d_counts, (void *)P.d_kdq, (void *)P.d_recs, P.d_shq_mem})
+        for (void *p : {(void *)P.d_counts, (void *)P.d_kdq, (void *)P.d_recs[0], (void *)P.d_recs[1], P.d_shq_mem[0], P.d_shq_mem[1]})
             if (p) (void)hipFree(p);
         if (P.h_counts) (void)hipHostFree(P.h_counts);
         for (auto &l : P.lv)
@@ -529,84 +535,129 @@ int rt_export_kdtree_reference(rt_ctx *ctx, uint32_t *nodes, int32_t *leaves, do
     return 0;
 }
 
-// launches the seven stages of level l of one part and the copy of its counters to the host
-static int launch_level(rt_ctx *ctx, Part &P, int l) {
+// launches pipeline step k of one part and the copy of the counters it changes to the host
+static int launch_step(rt_ctx *ctx, Part &P, int k) {
     const int D = ctx->cfg.max_depth;
     const SceneDev &sh = ctx->sh;
     const bool walk = sh.render_triangles && sh.use_kd;
-    const bool last = (l == D - 1);
-    const uint32_t n = P.n_rays[l];
+    const bool have_cur = k < D && P.n_rays[k] > 0;   // level k exists: its closest-hit half runs in this step
+    const bool have_prev = k >= 1;                    // level k-1 exists: its shadow half runs in this step
+    const bool last = (k == D - 1);
+    const uint32_t n = have_cur ? P.n_rays[k] : 0;
     hipStream_t s = P.stream;
-    if (!last) {
-        uint64_t want = std::min<uint64_t>(2ull * n, 0x7fffff00ull);
-        if (ensure_level(ctx, P, l + 1, (uint32_t)want)) return -1;
+    if (have_cur) {
+        if (!last) {
+            uint64_t want = std::min<uint64_t>(2ull * n, 0x7fffff00ull);
+            if (ensure_level(ctx, P, k + 1, (uint32_t)want)) return -1;
+        }
+        if (ensure_queues(ctx, P, k, n, (uint32_t)sh.n_lights)) return -1;
+        if (walk && P.cap_recs[0] == 0 && ensure(ctx, P.d_recs[0], P.cap_recs[0], std::max<size_t>((size_t)8 << 20, (size_t)n * 8))) return -1;
+        if (walk && P.cap_recs[1] == 0 && ensure(ctx, P.d_recs[1], P.cap_recs[1], std::max<size_t>((size_t)8 << 20, (size_t)n * 8))) return -1;
     }
-    if (ensure_queues(ctx, P, n, (uint32_t)sh.n_lights)) return -1;
-    if (walk && P.cap_recs == 0 && ensure(ctx, P.d_recs, P.cap_recs, std::max<size_t>((size_t)8 << 20, (size_t)n * 16))) return -1;
-    LevelArgs A{};
-    A.S = ctx->sh;
-    A.cur = P.lv[l].b;
-    if (!last) { A.nxt = P.lv[l + 1].b; A.nxt_cap = P.lv[l + 1].cap; }
-    A.shq = P.shq;
-    A.shq_cap = P.cap_shq;
-    A.kdq = P.d_kdq;
-    A.recs = P.d_recs;
-    A.rec_cap = (uint32_t)std::min<size_t>(P.cap_recs, 0x3fffff00u);
-    A.cnt = P.d_counts + l;
-    A.n_rays = n;
-    A.hit_ids = ctx->d_hit;
-    A.g = P.g;
-    A.level = l;
-    A.last_level = last ? 1 : 0;
-    WalkArgs Wk{ctx->sh, P.lv[l].b, P.shq, P.d_kdq, P.d_recs, P.d_counts + l, P.cap_shq, A.rec_cap};
-    const dim3 grid((n + BLOCK - 1) / BLOCK);
+    LevelArgs A{}, B{};
+    WalkArgs Wk{};
+    Wk.S = ctx->sh;
+    if (have_cur) {
+        A.S = ctx->sh;
+        A.cur = P.lv[k].b;
+        if (!last) { A.nxt = P.lv[k + 1].b; A.nxt_cap = P.lv[k + 1].cap; }
+        A.shq = P.shq[k & 1];
+        A.shq_cap = P.cap_shq[k & 1];
+        A.kdq = P.d_kdq;
+        A.recs = P.d_recs[0];
+        A.rec_cap = (uint32_t)std::min<size_t>(P.cap_recs[0], 0x3fffff00u);
+        A.cnt = P.d_counts + k;
+        A.n_rays = n;
+        A.hit_ids = ctx->d_hit;
+        A.g = P.g;
+        A.level = k;
+        A.last_level = last ? 1 : 0;
+        WalkJob &J = Wk.job[1];
+        J.rays = P.lv[k].b.ray;
+        J.kdq = P.d_kdq;
+        J.best = P.lv[k].b.best;
+        J.cnt = P.d_counts + k;
+        J.recs = P.d_recs[0];
+        J.rec_cap = A.rec_cap;
+        J.enabled = walk ? 1u : 0u;
+    }
+    if (have_prev) {
+        B.S = ctx->sh;
+        B.cur = P.lv[k - 1].b;
+        B.cnt = P.d_counts + (k - 1);
+        B.n_rays = P.n_rays[k - 1];
+        B.g = P.g;
+        B.level = k - 1;
+        B.last_level = (k - 1 == D - 1) ? 1 : 0;
+        WalkJob &J = Wk.job[0];
+        J.rays = P.shq[(k - 1) & 1].ray;
+        J.shq_id = P.shq[(k - 1) & 1].id;
+        J.shadow = P.lv[k - 1].b.shadow;
+        J.cnt = P.d_counts + (k - 1);
+        J.recs = P.d_recs[1];
+        J.rec_cap = (uint32_t)std::min<size_t>(P.cap_recs[1], 0x3fffff00u);
+        J.q_cap = P.cap_shq[(k - 1) & 1];
+        J.enabled = walk ? 1u : 0u;
+    }
+    const dim3 grid((n + BLOCK - 1) / BLOCK), grid_prev((B.n_rays + BLOCK - 1) / BLOCK);
     // persistent traversal waves: one 64-lane workgroup each (4 KB of LDS for the short stacks)
     const dim3 walk_grid((unsigned)ctx->n_cus * (unsigned)RT_WALK_WAVES_PER_CU);
     const dim3 test_grid((unsigned)ctx->n_cus * 32u);   // grid-stride over the records
-    hipEvent_t *ev = P.ev[l];
+    const bool any_walk = Wk.job[0].enabled || Wk.job[1].enabled;
+    hipEvent_t *ev = P.ev[k];
     HIPCK(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(k_gen_prims, grid, dim3(BLOCK), 0, s, A);
+    if (have_cur) hipLaunchKernelGGL(k_gen_prims, grid, dim3(BLOCK), 0, s, A);
     HIPCK(hipEventRecord(ev[1], s));
-    if (walk) hipLaunchKernelGGL(k_kd_walk<false>, walk_grid, dim3(WAVE), 0, s, Wk);
+    if (any_walk) hipLaunchKernelGGL(k_kd_walk, walk_grid, dim3(WAVE), 0, s, Wk);
     HIPCK(hipEventRecord(ev[2], s));
-    if (walk) hipLaunchKernelGGL(k_tri_test<false>, test_grid, dim3(256), 0, s, Wk);
+    if (any_walk) hipLaunchKernelGGL(k_tri_test, test_grid, dim3(256), 0, s, Wk);
     HIPCK(hipEventRecord(ev[3], s));
-    hipLaunchKernelGGL(k_shade_a, grid, dim3(BLOCK), 0, s, A);
+    if (have_prev) hipLaunchKernelGGL(k_shade_b, grid_prev, dim3(BLOCK), 0, s, B);
     HIPCK(hipEventRecord(ev[4], s));
-    if (walk) hipLaunchKernelGGL(k_kd_walk<true>, walk_grid, dim3(WAVE), 0, s, Wk);
-    HIPCK(hipEventRecord(ev[5], s));
-    if (walk) hipLaunchKernelGGL(k_tri_test<true>, test_grid, dim3(256), 0, s, Wk);
-    HIPCK(hipEventRecord(ev[6], s));
-    hipLaunchKernelGGL(k_shade_b, grid, dim3(BLOCK), 0, s, A);
+    if (have_cur) hipLaunchKernelGGL(k_shade_a, grid, dim3(BLOCK), 0, s, A);
     HIPCK(hipGetLastError());
-    HIPCK(hipEventRecord(ev[7], s));
-    HIPCK(hipMemcpyAsync(P.h_counts + l, P.d_counts + l, sizeof(LevelCounters), hipMemcpyDeviceToHost, s));
-    P.pending = l;
+    HIPCK(hipEventRecord(ev[5], s));
+    const int first = have_prev ? k - 1 : k, count = (have_prev ? 1 : 0) + (k < D ? 1 : 0);
+    HIPCK(hipMemcpyAsync(P.h_counts + first, P.d_counts + first, (size_t)count * sizeof(LevelCounters), hipMemcpyDeviceToHost, s));
+    P.pending = k;
     return 0;
 }
 
-// waits for the pending level of a part. One host round trip per level and part: the number of children sizes
-// the next level, and a walk that ran out of record space wrote nothing past the capacity, so the level is repeated
-// with a larger buffer. Returns 1 when the level has to be launched again, 0 when it is complete.
-static int collect_level(rt_ctx *ctx, Part &P) {
-    const int l = P.pending;
+// waits for the pending step of a part. One host round trip per step and part: the number of children sizes the
+// next level, and a walk that ran out of record space wrote nothing past the capacity, so the step is repeated with
+// a larger buffer (every stage of a step starts from the state the previous step left: the closest-hit half resets
+// its own counters' level, the shadow half only ever ORs bits in). Returns 1 when the step has to be launched again.
+static int collect_step(rt_ctx *ctx, Part &P) {
+    const int k = P.pending;
     const int D = ctx->cfg.max_depth;
     const bool walk = ctx->sh.render_triangles && ctx->sh.use_kd;
+    const bool have_cur = k < D && P.n_rays[k] > 0;
     HIPCK(hipStreamSynchronize(P.stream));
     P.pending = -1;
-    const LevelCounters &hc = P.h_counts[l];
-    const size_t need = std::max<size_t>(hc.rec_count[0], hc.rec_count[1]);
-    const size_t rec_cap = std::min<size_t>(P.cap_recs, 0x3fffff00u);
-    if (walk && need > rec_cap) {
-        if (P.attempt >= 3 || need > 0x3fffff00u) return fail(ctx, "rt_trace: triangle record buffer cannot hold one level");
-        if (ensure(ctx, P.d_recs, P.cap_recs, need + need / 4)) return -1;
-        HIPCK(hipMemsetAsync(P.d_counts + l, 0, sizeof(LevelCounters), P.stream));
+    const size_t need0 = have_cur ? P.h_counts[k].rec_count[0] : 0;
+    const size_t need1 = k >= 1 ? P.h_counts[k - 1].rec_count[1] : 0;
+    const bool over0 = walk && need0 > std::min<size_t>(P.cap_recs[0], 0x3fffff00u);
+    const bool over1 = walk && need1 > std::min<size_t>(P.cap_recs[1], 0x3fffff00u);
+    if (over0 || over1) {
+        if (P.attempt >= 3 || need0 > 0x3fffff00u || need1 > 0x3fffff00u) return fail(ctx, "rt_trace: leaf record buffer cannot hold one level");
+        if (over0 && ensure(ctx, P.d_recs[0], P.cap_recs[0], need0 + need0 / 4)) return -1;
+        if (over1 && ensure(ctx, P.d_recs[1], P.cap_recs[1], need1 + need1 / 4)) return -1;
+        if (have_cur) HIPCK(hipMemsetAsync(P.d_counts + k, 0, sizeof(LevelCounters), P.stream));
+        if (k >= 1) {   // the previous level keeps its queue length; its queue cursor and shadow record count start over
+            LevelCounters *c = P.d_counts + (k - 1);
+            HIPCK(hipMemsetAsync(&c->shq_head, 0, sizeof(uint32_t), P.stream));
+            HIPCK(hipMemsetAsync(&c->rec_count[1], 0, sizeof(uint32_t), P.stream));
+        }
         P.attempt++;
         return 1;
     }
     P.attempt = 0;
-    if (l < D - 1) P.n_rays[l + 1] = std::min(hc.next_count, P.lv[l + 1].cap);
-    P.levels_run = l + 1;
+    P.rec_total[0] += need0;
+    P.rec_total[1] += need1;
+    if (have_cur) {
+        if (k < D - 1) P.n_rays[k + 1] = std::min(P.h_counts[k].next_count, P.lv[k + 1].cap);
+        P.levels_run = k + 1;
+    }
     return 0;
 }
 
@@ -618,32 +669,34 @@ int rt_trace(rt_ctx *ctx) {
     const int D = ctx->cfg.max_depth;
     const SceneDev &sh = ctx->sh;
     const int NP = ctx->n_parts;
-    // level 0 of every part goes out first; from then on a part's next level is launched as soon as its
-    // counters are back, while the other parts keep the GPU busy
+    // step 0 of every part goes out first; from then on a part's next step is launched as soon as its counters
+    // are back, while the other parts keep the GPU busy
     for (int p = 0; p < NP; p++) {
         Part &P = ctx->parts[p];
         P.levels_run = 0;
         P.pending = -1;
         P.attempt = 0;
+        P.rec_total[0] = P.rec_total[1] = 0;
         memset(P.n_rays, 0, sizeof P.n_rays);
         P.n_rays[0] = P.n0;
         HIPCK(hipMemsetAsync(P.d_counts, 0, MAX_LEVELS * sizeof(LevelCounters), P.stream));
         HIPCK(hipEventRecord(P.ev_begin, P.stream));
         if (P.n0 == 0) continue;
         if (ensure_level(ctx, P, 0, P.n0)) return -1;
-        if (launch_level(ctx, P, 0)) return -1;
+        if (launch_step(ctx, P, 0)) return -1;
     }
     for (bool busy = true; busy;) {
         busy = false;
         for (int p = 0; p < NP; p++) {
             Part &P = ctx->parts[p];
             if (P.pending < 0) continue;
-            const int l = P.pending;
-            const int again = collect_level(ctx, P);
+            const int k = P.pending;
+            const int again = collect_step(ctx, P);
             if (again < 0) return -1;
-            int next = again ? l : l + 1;
-            if (next < D && P.n_rays[next] > 0) {
-                if (launch_level(ctx, P, next)) return -1;
+            // step k+1 exists while level k existed: it finishes that level's shadow rays
+            const int next = again ? k : k + 1;
+            if (next <= D && (next == k || P.levels_run == k + 1)) {
+                if (launch_step(ctx, P, next)) return -1;
                 busy = true;
             }
         }
@@ -681,32 +734,29 @@ int rt_trace(rt_ctx *ctx) {
     // GPU, so these are occupancy-weighted durations, not exclusive ones
     for (int p = 0; p < NP; p++) {
         const Part &P = ctx->parts[p];
+        st.tri_records[0] += P.rec_total[0];
+        st.tri_records[1] += P.rec_total[1];
         for (int l = 1; l < P.levels_run; l++) st.rays_per_level[l] += P.n_rays[l];
         for (int l = 0; l < P.levels_run; l++) {
             const LevelCounters &hc = P.h_counts[l];
             st.shadow_rays += (uint64_t)hc.shaded * (uint64_t)sh.n_lights;
             st.kd_closest_rays += hc.kdq_count;
             st.kd_shadow_rays += hc.shq_count;
-            st.tri_records[0] += hc.rec_count[0];
-            st.tri_records[1] += hc.rec_count[1];
 #ifdef RT_WALK_STATS
             fprintf(stderr, "walk stats part %d level %d: closest iters %llu visits %llu | shadow iters %llu visits %llu\n", p, l,
                     hc.walk_iters[0], hc.walk_visits[0], hc.walk_iters[1], hc.walk_visits[1]);
-            for (int k = 0; k < 2; k++) {
-                const double span = (double)(hc.walk_t1[k] - ~hc.walk_t0[k]) * 0.01;   // microseconds
-                const double mean = (double)hc.walk_tsum[k] * 0.01 / ((double)ctx->n_cus * RT_WALK_WAVES_PER_CU);
-                fprintf(stderr, "    %s walk: first wave start to last wave end %.1f us, mean wave lifetime %.1f us (%.0f%% of the span)\n",
-                        k ? "shadow " : "closest", span, mean, span > 0 ? 100.0 * mean / span : 0.0);
-            }
 #endif
+        }
+        const int steps = P.levels_run ? P.levels_run + 1 : 0;
+        for (int k = 0; k < steps && k < MAX_STEPS; k++) {
             float ms = 0;
-            for (int k = 0; k < N_STAGES; k++) {
-                HIPCK(hipEventElapsedTime(&ms, P.ev[l][k], P.ev[l][k + 1]));
-                st.level_stage_ms[l][k] += ms;
-                st.stage_ms[k] += ms;
+            for (int j = 0; j < N_STAGES; j++) {
+                HIPCK(hipEventElapsedTime(&ms, P.ev[k][j], P.ev[k][j + 1]));
+                if (k < 8) st.level_stage_ms[k][j] += ms;
+                st.stage_ms[j] += ms;
             }
-            HIPCK(hipEventElapsedTime(&ms, P.ev[l][0], P.ev[l][N_STAGES]));
-            st.level_kernel_ms[l] += ms;
+            HIPCK(hipEventElapsedTime(&ms, P.ev[k][0], P.ev[k][N_STAGES]));
+            if (k < 8) st.level_kernel_ms[k] += ms;
         }
         float ms = 0;
         HIPCK(hipEventElapsedTime(&ms, ctx->parts[0].ev_begin, P.ev_end));

@@ -218,14 +218,24 @@ __global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
 // cell - so a restart re-derives exactly the dropped decisions.
 // Every lane owns one ray and takes one tree action per iteration (a descent step, or at a leaf: list its
 // triangles and pop); a lane whose ray is finished pulls the next one from the global queue.
+// The walk and the triangle tests of one pipeline step serve two queues in one launch: job 0 = the shadow rays of
+// the previous ray-tree level, job 1 = the closest-hit rays of the current one. The two are independent (the
+// children of a level are spawned before its shadow rays are walked), and one launch lets the waves that run out
+// of shadow rays move straight on to the closest-hit queue instead of idling until the slowest shadow ray is done.
+struct WalkJob {
+    const float4 *rays;        // job 0: shadow queue records (origin + entry distance, direction + exit distance); job 1: ray records of the level
+    const uint4 *kdq;          // job 1: (ray index, root-box entry distance, exit distance, -)
+    const uint32_t *shq_id;    // job 0: ray index << 5 | light
+    uint32_t *shadow;          // job 0: shadow bits of the level the shadow rays belong to
+    unsigned long long *best;  // job 1: closest mesh hit keys of the level
+    LevelCounters *cnt;        // counters of the job's level
+    uint2 *recs;               // (ray reference, leaf face count << 27 | first slot in S.ltris)
+    uint32_t rec_cap, q_cap;
+    uint32_t enabled, pad;
+};
 struct WalkArgs {
     SceneDev S;
-    LevelBuf cur;
-    ShadowQ shq;
-    const uint4 *kdq;
-    uint2 *recs;            // out: (ray reference, leaf face count << 27 | first slot in S.ltris)
-    LevelCounters *cnt;
-    uint32_t shq_cap, rec_cap;
+    WalkJob job[2];
 };
 
 #if defined(RT_DBG_NO_EMIT)
@@ -258,15 +268,11 @@ constexpr int SHORT_STACK = RT_SHORT_STACK;          // power of two
 constexpr uint32_t REC_FILLER = 0u;   // a record's second word is count << 27 | first slot; count 0 = filler
 
 template <bool ANY>
-__global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
-    __shared__ uint2 s_stack[SHORT_STACK * WAVE];
-    const SceneDev &S = A.S;
+__device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, uint2 *stack, const uint32_t lane) {
     const KdNodeDev *__restrict__ nodes = S.nodes;
-    const uint32_t lane = threadIdx.x;
-    uint2 *stack = s_stack + lane;
-    const uint32_t total = ANY ? min(A.cnt->shq_count, A.shq_cap) : A.cnt->kdq_count;
-    uint32_t *head = ANY ? &A.cnt->shq_head : &A.cnt->kdq_head;
-    uint32_t *rec_count = &A.cnt->rec_count[ANY ? 1 : 0];
+    const uint32_t total = ANY ? min(J.cnt->shq_count, J.q_cap) : J.cnt->kdq_count;
+    uint32_t *head = ANY ? &J.cnt->shq_head : &J.cnt->kdq_head;
+    uint32_t *rec_count = &J.cnt->rec_count[ANY ? 1 : 0];
     const KdNodeDev root = nodes[0];
 
     // wave-uniform values are passed through readfirstlane so that they live in scalar registers and
@@ -317,15 +323,15 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
                 if (info == 0u && q < total) {
                     if (ANY) {
                         ref = q;
-                        const float4 fo = A.shq.ray[2 * (size_t)q], fd = A.shq.ray[2 * (size_t)q + 1];
+                        const float4 fo = J.rays[2 * (size_t)q], fd = J.rays[2 * (size_t)q + 1];
                         ox = fo.x; oy = fo.y; oz = fo.z; tmin = fo.w;
                         dx = fd.x; dy = fd.y; dz = fd.z; maxDist = fd.w;
                     } else {
-                        const uint4 e = A.kdq[q];
+                        const uint4 e = J.kdq[q];
                         ref = e.x;
                         tmin = __uint_as_float(e.y);
                         maxDist = __uint_as_float(e.z);
-                        const float4 fo = A.cur.ray[2 * (size_t)ref], fd = A.cur.ray[2 * (size_t)ref + 1];
+                        const float4 fo = J.rays[2 * (size_t)ref], fd = J.rays[2 * (size_t)ref + 1];
                         ox = fo.x; oy = fo.y; oz = fo.z;
                         dx = fd.x; dy = fd.y; dz = fd.z;
                     }
@@ -395,35 +401,42 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
         if (listed) {
             const uint32_t tot = COUNT_OF(listed);
             if (rec_end - rec_pos < tot) {
-                for (uint32_t p = rec_pos + lane; p < rec_end; p += WAVE) A.recs[p] = make_uint2(0u, REC_FILLER);
+                for (uint32_t p = rec_pos + lane; p < rec_end; p += WAVE) J.recs[p] = make_uint2(0u, REC_FILLER);
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(rec_count, (uint32_t)REC_CHUNK);
                 base = UNIFORM(base);
                 rec_pos = base;
                 // past the capacity nothing is written; the host sees rec_count > capacity and repeats
                 // the level with a larger buffer
-                rec_end = (base + (uint32_t)REC_CHUNK <= A.rec_cap) ? base + (uint32_t)REC_CHUNK : base;
+                rec_end = (base + (uint32_t)REC_CHUNK <= J.rec_cap) ? base + (uint32_t)REC_CHUNK : base;
             }
             if (rec_end - rec_pos >= tot) {
-                if (is_listed) A.recs[rec_pos + RANK_IN(listed)] = make_uint2(ref, leaf_info);
+                if (is_listed) J.recs[rec_pos + RANK_IN(listed)] = make_uint2(ref, leaf_info);
                 rec_pos += tot;
             }
         }
     }
-    for (uint32_t p = rec_pos + lane; p < rec_end; p += WAVE) A.recs[p] = make_uint2(0u, REC_FILLER);
+    for (uint32_t p = rec_pos + lane; p < rec_end; p += WAVE) J.recs[p] = make_uint2(0u, REC_FILLER);
 #ifdef RT_WALK_STATS
     if (lane == 0) {
-        atomicAdd(&A.cnt->walk_iters[ANY ? 1 : 0], st_iters);
-        atomicAdd(&A.cnt->walk_visits[ANY ? 1 : 0], st_visits);
+        atomicAdd(&J.cnt->walk_iters[ANY ? 1 : 0], st_iters);
+        atomicAdd(&J.cnt->walk_visits[ANY ? 1 : 0], st_visits);
         const unsigned long long st_end = wall_clock64();
-        atomicMax(&A.cnt->walk_t0[ANY ? 1 : 0], ~st_begin);   // counters start at zero: the minimum is kept as the maximum of the complement
-        atomicMax(&A.cnt->walk_t1[ANY ? 1 : 0], st_end);
-        atomicAdd(&A.cnt->walk_tsum[ANY ? 1 : 0], st_end - st_begin);
+        atomicMax(&J.cnt->walk_t0[ANY ? 1 : 0], ~st_begin);   // counters start at zero: the minimum is kept as the maximum of the complement
+        atomicMax(&J.cnt->walk_t1[ANY ? 1 : 0], st_end);
+        atomicAdd(&J.cnt->walk_tsum[ANY ? 1 : 0], st_end - st_begin);
     }
 #endif
 #undef RANK_IN
 #undef COUNT_OF
 #undef UNIFORM
+}
+
+__global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
+    __shared__ uint2 s_stack[SHORT_STACK * WAVE];
+    const uint32_t lane = threadIdx.x;
+    if (A.job[0].enabled) walk_job<true>(A.S, A.job[0], s_stack + lane, lane);
+    if (A.job[1].enabled) walk_job<false>(A.S, A.job[1], s_stack + lane, lane);
 }
 
 // ---- triangle tests over the records of a walk -------------------------------------------------------------
@@ -432,24 +445,19 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
 // the buffer in visit order, so the 64-bit key (t bits, record index * 4 + face slot) ordered by an atomic min
 // reproduces that. (Record indices stay below 2^30: the buffer capacity is capped accordingly.)
 template <bool ANY>
-__global__ __launch_bounds__(256) void k_tri_test(WalkArgs A) {
-    const SceneDev &S = A.S;
-    const uint32_t n_rec = min(A.cnt->rec_count[ANY ? 1 : 0], A.rec_cap);
+__device__ __forceinline__ void test_job(const SceneDev &S, const WalkJob &J) {
+    const uint32_t n_rec = min(J.cnt->rec_count[ANY ? 1 : 0], J.rec_cap);
     for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
-        const uint2 rec = A.recs[r];
+        const uint2 rec = J.recs[r];
         const uint32_t count = rec.y >> LEAF_COUNT_SHIFT, first = rec.y & LEAF_SLOT_MASK;
         if (count == 0u) continue;
-        V3 ro, rd;
         uint32_t id = 0;
         if (ANY) {
-            id = A.shq.id[rec.x];
-            if (A.cur.shadow[id >> 5] & (1u << (id & 31u))) continue;   // already known to be occluded
-            const float4 o = A.shq.ray[2 * (size_t)rec.x], d = A.shq.ray[2 * (size_t)rec.x + 1];
-            ro = v3(o.x, o.y, o.z);
-            rd = v3(d.x, d.y, d.z);
-        } else {
-            load_ray(A.cur.ray, rec.x, ro, rd);
+            id = J.shq_id[rec.x];
+            if (J.shadow[id >> 5] & (1u << (id & 31u))) continue;   // already known to be occluded
         }
+        V3 ro, rd;
+        load_ray(J.rays, rec.x, ro, rd);
         unsigned long long key = ~0ull;
         for (uint32_t k = 0; k < count; k++) {
             float t;
@@ -462,10 +470,15 @@ __global__ __launch_bounds__(256) void k_tri_test(WalkArgs A) {
             }
         }
         if (key != ~0ull) {
-            if (ANY) atomicOr(&A.cur.shadow[id >> 5], 1u << (id & 31u));
-            else atomicMin(&A.cur.best[rec.x], key);
+            if (ANY) atomicOr(&J.shadow[id >> 5], 1u << (id & 31u));
+            else atomicMin(&J.best[rec.x], key);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_tri_test(WalkArgs A) {
+    if (A.job[0].enabled) test_job<true>(A.S, A.job[0]);
+    if (A.job[1].enabled) test_job<false>(A.S, A.job[1]);
 }
 
 // ---- surface reconstruction ------------------------------------------------------------------------
@@ -573,6 +586,68 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
         }
     }
     if (in_range) A.cur.shadow[tid] = occluded_mask;
+    // children (js/8-kd_tree.js:1010-1036). They depend on the hit only, not on the shadow rays, so they are spawned
+    // here: the next level's closest-hit walk then runs together with this level's shadow walk.
+    bool want_refl = false, want_refr = false;
+    V3 c_refl_o = v3(0, 0, 0), c_refl_d = v3(0, 0, 0), c_refr_o = v3(0, 0, 0), c_refr_d = v3(0, 0, 0);
+    float kReflect = 0.0f, kRefract = 0.0f;
+    if (hit && sf.mat >= 0) {
+        const MatDev &m = S.mats[sf.mat];
+        kReflect = m.kReflect; kRefract = m.kRefract;
+        const float ior = m.ior;
+        if (!A.last_level) {   // neither child direction is normalised (js/8-kd_tree.js:1022, :1033)
+            bool outside = dot(rd, sf.normal) < 0.0f;
+            V3 bias = sf.normal * S.eps;
+            if (kRefract > S.eps && ior > S.eps) {
+                want_refr = true;
+                c_refr_o = outside ? (sf.point - bias) : (sf.point + bias);
+                V3 Nn = outside ? sf.normal : -sf.normal;
+                float eta = outside ? (1.0f / ior) : ior;
+                float cosi = dot(-Nn, rd);
+                float k = 1.0f + eta * eta * (cosi * cosi - 1.0f);
+                c_refr_d = rd * eta + Nn * (eta * cosi - sqrtf(k));
+            }
+            if (kReflect > S.eps) {
+                want_refl = true;
+                c_refl_o = outside ? (sf.point + bias) : (sf.point - bias);
+                c_refl_d = rd - sf.normal * (2.0f * dot(sf.normal, rd));
+            }
+        }
+    }
+    int32_t slot_refl = -1, slot_refr = -1;
+    if (!A.last_level) {
+        // the refracted ray takes the lane's first slot, the reflected one the next
+        uint32_t cs = block_reserve((want_refr ? 1u : 0u) + (want_refl ? 1u : 0u), &A.cnt->next_count, s_wave);
+        if (want_refr) {
+            if (cs < A.nxt_cap) {
+                slot_refr = (int32_t)cs;
+                store_ray(A.nxt.ray, cs, c_refr_o, c_refr_d);
+            }
+            cs++;
+        }
+        if (want_refl && cs < A.nxt_cap) {
+            slot_refl = (int32_t)cs;
+            store_ray(A.nxt.ray, cs, c_refl_o, c_refl_d);
+        }
+    }
+    {   // shaded nodes of this level (shadow rays = shaded nodes x lights)
+        const unsigned long long m = __ballot(hit);
+        if (threadIdx.x == 0) s_wave[0] = 0u;
+        __syncthreads();
+        if (m && lane_id() == 0) atomicAdd(&s_wave[0], (uint32_t)__popcll(m));
+        __syncthreads();
+        if (threadIdx.x == 0 && s_wave[0]) atomicAdd(&A.cnt->shaded, s_wave[0]);
+        __syncthreads();
+    }
+    if (hit) {
+        A.cur.kr[tid] = kReflect; A.cur.kt[tid] = kRefract;
+        A.cur.refl[tid] = slot_refl; A.cur.refr[tid] = slot_refr;
+        if (A.level == 0) {
+            int px, py;
+            pixel_of(A.g, tid, px, py);
+            A.hit_ids[(size_t)py * A.g.W + px] = sf.hit_id;
+        }
+    }
     // shadow rays that must walk the tree: one reservation for the whole workgroup
     uint32_t slot = block_reserve((uint32_t)__popc(kd_mask), &A.cnt->shq_count, s_wave);
     while (kd_mask) {
@@ -589,9 +664,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
     }
 }
 
-// ---- stage 5: illuminate (js/8-kd_tree.js:716-820) + children (js/8-kd_tree.js:1010-1036) ---------------
+// ---- illuminate (js/8-kd_tree.js:716-820): the local colour of every hit, with the finished shadow bits ----
 __global__ __launch_bounds__(BLOCK) void k_shade_b(LevelArgs A) {
-    __shared__ uint32_t s_wave[BLOCK / WAVE + 1];
     const SceneDev &S = A.S;
     const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x;
     const bool in_range = tid < A.n_rays;
@@ -602,10 +676,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_b(LevelArgs A) {
     load_ray(A.cur.ray, i, ro, rd);
     Surface sf;
     const bool hit = active && make_surface(S, ro, rd, A.cur.ht[i], hp, A.cur.hf[i], sf);
-    bool want_refl = false, want_refr = false;
-    V3 c_refl_o = v3(0, 0, 0), c_refl_d = v3(0, 0, 0), c_refr_o = v3(0, 0, 0), c_refr_d = v3(0, 0, 0);
     V3 color = v3(0, 0, 0);
-    float kReflect = 0.0f, kRefract = 0.0f, ior = 0.0f;
     if (hit) {
         const uint32_t mask = A.cur.shadow[i];
         float ka = 0.0f, kd = 0.0f, ks = 0.0f, ke = 0.0f;
@@ -615,7 +686,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade_b(LevelArgs A) {
             const MatDev &m = S.mats[sf.mat];
             mtype = m.type;
             ka = m.ka; kd = m.kd; ks = m.ks; ke = m.ke;
-            kReflect = m.kReflect; kRefract = m.kRefract; ior = m.ior;
             Cs = ld3(m.Cs);
             if (m.type == RT_MAT_PHONG_CHECKERED) {   // js/8-kd_tree.js:755-776
                 float u = sf.local.x + 0.5f, v = sf.local.z + 0.5f;
@@ -655,58 +725,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade_b(LevelArgs A) {
             }
         }
         color = v3(0, 0, 0) + ((ambient + specular) + diffuse);
-        if (!A.last_level) {   // neither child direction is normalised (js/8-kd_tree.js:1022, :1033)
-            bool outside = dot(rd, sf.normal) < 0.0f;
-            V3 bias = sf.normal * S.eps;
-            if (kRefract > S.eps && ior > S.eps) {
-                want_refr = true;
-                c_refr_o = outside ? (sf.point - bias) : (sf.point + bias);
-                V3 Nn = outside ? sf.normal : -sf.normal;
-                float eta = outside ? (1.0f / ior) : ior;
-                float cosi = dot(-Nn, rd);
-                float k = 1.0f + eta * eta * (cosi * cosi - 1.0f);
-                c_refr_d = rd * eta + Nn * (eta * cosi - sqrtf(k));
-            }
-            if (kReflect > S.eps) {
-                want_refl = true;
-                c_refl_o = outside ? (sf.point + bias) : (sf.point - bias);
-                c_refl_d = rd - sf.normal * (2.0f * dot(sf.normal, rd));
-            }
-        }
-    }
-    int32_t slot_refl = -1, slot_refr = -1;
-    if (!A.last_level) {
-        // children: the refracted ray takes the lane's first slot, the reflected one the next
-        uint32_t slot = block_reserve((want_refr ? 1u : 0u) + (want_refl ? 1u : 0u), &A.cnt->next_count, s_wave);
-        if (want_refr) {
-            if (slot < A.nxt_cap) {
-                slot_refr = (int32_t)slot;
-                store_ray(A.nxt.ray, slot, c_refr_o, c_refr_d);
-            }
-            slot++;
-        }
-        if (want_refl && slot < A.nxt_cap) {
-            slot_refl = (int32_t)slot;
-            store_ray(A.nxt.ray, slot, c_refl_o, c_refl_d);
-        }
-    }
-    {   // shaded nodes of this level (shadow rays = shaded nodes x lights)
-        const unsigned long long m = __ballot(hit);
-        if (threadIdx.x == 0) s_wave[0] = 0u;
-        __syncthreads();
-        if (m && lane_id() == 0) atomicAdd(&s_wave[0], (uint32_t)__popcll(m));
-        __syncthreads();
-        if (threadIdx.x == 0 && s_wave[0]) atomicAdd(&A.cnt->shaded, s_wave[0]);
     }
     if (hit) {
         A.cur.cr[tid] = color.x; A.cur.cg[tid] = color.y; A.cur.cb[tid] = color.z;
-        A.cur.kr[tid] = kReflect; A.cur.kt[tid] = kRefract;
-        A.cur.refl[tid] = slot_refl; A.cur.refr[tid] = slot_refr;
-        if (A.level == 0) {
-            int px, py;
-            pixel_of(A.g, tid, px, py);
-            A.hit_ids[(size_t)py * A.g.W + px] = sf.hit_id;
-        }
     }
 }
 
