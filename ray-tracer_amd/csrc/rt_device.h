@@ -42,8 +42,29 @@ struct TriDev {
     float v0[3], e1[3], e2[3];
     int32_t mat;
     int32_t face;
-    int32_t pad;
+    uint32_t code;                // `ltris` only: path code of the leaf that lists this slot (see path_code)
 };
+
+// Position of a node in the tree as a bit string: one bit per level below the root, 0 = lower child, 1 = upper
+// child, left-aligned in PATH_BITS bits and padded with zeros. Leaves are prefix-free, so the code names a leaf.
+// For one ray the traversal always enters the NEAR child of a node first (js/8-kd_tree.js:888-930), and which child
+// is near depends only on the sign of the direction component of the node's axis; the axis of level i is i % 3
+// (js/8-kd_tree.js:872). Flipping the bits of the levels whose axis the ray runs down therefore turns the code into
+// a number that grows in the order in which the ray visits the leaves, whatever order they are processed in.
+constexpr int PATH_BITS = 23;   // the depth cap of 24 (root = 1) leaves at most 23 decisions
+constexpr uint32_t axis_levels(int axis) {
+    uint32_t m = 0;
+    for (int i = axis; i < PATH_BITS; i += 3) m |= 1u << (PATH_BITS - 1 - i);
+    return m;
+}
+constexpr uint32_t PATH_X = axis_levels(0), PATH_Y = axis_levels(1), PATH_Z = axis_levels(2);
+// heap index (children 2h+1, 2h+2, js/8-kd_tree.js:1632-1645): h+1 in binary is a leading 1 followed by the path
+inline uint32_t path_code(uint32_t heap) {
+    const uint32_t x = heap + 1u;
+    int depth = 0;
+    while ((x >> depth) > 1u) depth++;
+    return depth > PATH_BITS ? 0u : (x ^ (1u << depth)) << (PATH_BITS - depth);
+}
 
 // Device copy of a k-d node (see kd_build.h for internal nodes). Leaf info differs from the host form:
 // [31:30] = 3, [29:27] = number of faces (1..4), [26:0] = first slot in `ltris`.
@@ -63,6 +84,7 @@ struct SceneDev {
     const TriDev *tris;
     const KdNodeDev *nodes;
     const TriDev *ltris;
+    const uint32_t *path_slot;    // path code of a non-empty leaf -> its first slot in `ltris` (2^PATH_BITS entries)
 };
 
 struct V3 {
@@ -281,6 +303,11 @@ __device__ __forceinline__ bool hit_tri_regs(V3 v0, V3 e1, V3 e2, float tri_eps,
 }
 __device__ __forceinline__ bool hit_tri(const TriDev &T, float tri_eps, V3 ro, V3 rd, float &t) {
     return hit_tri_regs(ld3(T.v0), ld3(T.e1), ld3(T.e2), tri_eps, ro, rd, t);
+}
+
+// the levels at which this ray's near child is the upper one (`dir <= 0`, js/8-kd_tree.js:888)
+__device__ __forceinline__ uint32_t near_upper_levels(V3 rd) {
+    return (rd.x <= 0.0f ? PATH_X : 0u) | (rd.y <= 0.0f ? PATH_Y : 0u) | (rd.z <= 0.0f ? PATH_Z : 0u);
 }
 
 // intersectRayAABB, js/8-kd_tree.js:545-573 (its boolean result is never used by the callers)

@@ -93,8 +93,10 @@ struct rt_ctx {
     TriDev *d_tris = nullptr;
     KdNodeDev *d_nodes = nullptr;
     TriDev *d_ltris = nullptr;
+    uint2 *d_path_first = nullptr;               // staging of (path code, first slot) pairs
+    uint32_t *d_path_slot = nullptr;             // 2^PATH_BITS entries, SceneDev::path_slot
     bool tree_dirty = true;
-    size_t cap_prims = 0, cap_mats = 0, cap_lights = 0, cap_tris = 0, cap_nodes = 0, cap_ltris = 0;
+    size_t cap_prims = 0, cap_mats = 0, cap_lights = 0, cap_tris = 0, cap_nodes = 0, cap_ltris = 0, cap_path_first = 0;
     // frame
     FrameGeom g{};                               // the whole shard
     uint32_t n0 = 0;                             // level-0 entries = tiles of this shard * 64
@@ -220,7 +222,7 @@ int upload_scene(rt_ctx *ctx) {
             for (int k = 0; k < 3; k++) { t.v0[k] = v[0][k]; t.e1[k] = v[1][k] - v[0][k]; t.e2[k] = v[2][k] - v[0][k]; }
             t.mat = find_mat((int)ctx->face_mat[2 * f], (int)ctx->face_mat[2 * f + 1]);
             t.face = (int32_t)f;
-            t.pad = 0;
+            t.code = 0;
         }
         if (ensure(ctx, ctx->d_tris, ctx->cap_tris, nf)) return -1;
         if (nf) HIPCK(hipMemcpyAsync(ctx->d_tris, tris.data(), nf * sizeof(TriDev), hipMemcpyHostToDevice, ctx->stream));
@@ -247,15 +249,31 @@ int upload_scene(rt_ctx *ctx) {
                 if (kd.leaves[i].face[k] > -1) ltris[s0++] = ctx->tris_host[(size_t)kd.leaves[i].face[k]];
         }
         std::vector<KdNodeDev> nodes(kd.nodes);
-        for (auto &n : nodes)
+        std::vector<uint2> path_first;   // (path code, first slot) of every non-empty leaf
+        path_first.reserve(kd.leaves.size());
+        for (size_t s = 0; s < nodes.size(); s++) {
+            KdNodeDev &n = nodes[s];
             if ((n.info >> 30) == 3u) {
                 const uint32_t li = n.info & 0x3fffffffu;
                 n.info = (3u << 30) | ((first[li + 1] - first[li]) << LEAF_COUNT_SHIFT) | first[li];
+                const uint32_t code = path_code(kd.heap_index[s]);
+                for (uint32_t k = first[li]; k < first[li + 1]; k++) ltris[k].code = code;
+                path_first.push_back(make_uint2(code, first[li]));
             }
+        }
         if (ensure(ctx, ctx->d_nodes, ctx->cap_nodes, nodes.size())) return -1;
         if (ensure(ctx, ctx->d_ltris, ctx->cap_ltris, ltris.size())) return -1;
+        if (ensure(ctx, ctx->d_path_first, ctx->cap_path_first, path_first.size())) return -1;
+        if (!ctx->d_path_slot) HIPCK(hipMalloc((void **)&ctx->d_path_slot, sizeof(uint32_t) << PATH_BITS));
         HIPCK(hipMemcpyAsync(ctx->d_nodes, nodes.data(), nodes.size() * sizeof(KdNodeDev), hipMemcpyHostToDevice, ctx->stream));
         if (!ltris.empty()) HIPCK(hipMemcpyAsync(ctx->d_ltris, ltris.data(), ltris.size() * sizeof(TriDev), hipMemcpyHostToDevice, ctx->stream));
+        if (!path_first.empty()) {
+            // only the entries of existing leaves are ever read, so the table is not cleared
+            HIPCK(hipMemcpyAsync(ctx->d_path_first, path_first.data(), path_first.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_fill_path_slots, dim3((unsigned)((path_first.size() + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->d_path_first, (uint32_t)path_first.size(), ctx->d_path_slot);
+            HIPCK(hipGetLastError());
+        }
         HIPCK(hipStreamSynchronize(ctx->stream));
         ctx->st.kd_upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         ctx->tree_dirty = false;
@@ -279,7 +297,7 @@ int upload_scene(rt_ctx *ctx) {
         }
     }
     h.prims = ctx->d_prims; h.mats = ctx->d_mats; h.lights = ctx->d_lights; h.tris = ctx->d_tris;
-    h.nodes = ctx->d_nodes; h.ltris = ctx->d_ltris;
+    h.nodes = ctx->d_nodes; h.ltris = ctx->d_ltris; h.path_slot = ctx->d_path_slot;
     HIPCK(hipMemcpyAsync(ctx->d_scene, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
     HIPCK(hipStreamSynchronize(ctx->stream));
     ctx->scene_dirty = false;
@@ -407,7 +425,7 @@ void rt_destroy(rt_ctx *ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     (void)hipDeviceSynchronize();
     void *ptrs[] = {ctx->d_scene, ctx->d_prims, ctx->d_mats, ctx->d_lights, ctx->d_tris, ctx->d_nodes, ctx->d_ltris,
-                    ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_canvas,
+                    ctx->d_path_first, ctx->d_path_slot, ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_canvas,
                     ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -441,9 +441,10 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
 
 // ---- triangle tests over the records of a walk -------------------------------------------------------------
 // Closest hit: the shader tests a leaf's faces in order and keeps a hit only if `hitInfo.t < tMin`
-// (js/8-kd_tree.js:948-949), i.e. among equal distances the face met FIRST wins. Records of one ray sit in
-// the buffer in visit order, so the 64-bit key (t bits, record index * 4 + face slot) ordered by an atomic min
-// reproduces that. (Record indices stay below 2^30: the buffer capacity is capped accordingly.)
+// (js/8-kd_tree.js:948-949), i.e. among equal distances the face met FIRST wins. The 64-bit key
+// (t bits, visit rank of the leaf for this ray, face position in the leaf) ordered by an atomic min reproduces
+// that without any assumption on the order in which the records were written; the key also names the winner:
+// rank ^ near_upper_levels(direction) is the leaf's path code, SceneDev::path_slot maps it to the leaf's slots.
 template <bool ANY>
 __device__ __forceinline__ void test_job(const SceneDev &S, const WalkJob &J) {
     const uint32_t n_rec = min(J.cnt->rec_count[ANY ? 1 : 0], J.rec_cap);
@@ -458,13 +459,15 @@ __device__ __forceinline__ void test_job(const SceneDev &S, const WalkJob &J) {
         }
         V3 ro, rd;
         load_ray(J.rays, rec.x, ro, rd);
+        // visit rank of this leaf for this ray (see path_code) and the face's position in the leaf
+        const uint32_t order = ANY ? 0u : ((S.ltris[first].code ^ near_upper_levels(rd)) << 2);
         unsigned long long key = ~0ull;
         for (uint32_t k = 0; k < count; k++) {
             float t;
             if (hit_tri(S.ltris[first + k], S.tri_eps, ro, rd, t)) {
                 // t >= 0 here, so the float bits order like the values; -0 is folded onto +0
                 const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);
-                const unsigned long long kk = ((unsigned long long)tb << 32) | (unsigned long long)(r * 4u + k);
+                const unsigned long long kk = ((unsigned long long)tb << 32) | (unsigned long long)(order | k);
                 key = kk < key ? kk : key;
                 if (ANY) break;
             }
@@ -479,6 +482,12 @@ __device__ __forceinline__ void test_job(const SceneDev &S, const WalkJob &J) {
 __global__ __launch_bounds__(256) void k_tri_test(WalkArgs A) {
     if (A.job[0].enabled) test_job<true>(A.S, A.job[0]);
     if (A.job[1].enabled) test_job<false>(A.S, A.job[1]);
+}
+
+// (path code, first slot) of every non-empty leaf -> SceneDev::path_slot
+__global__ __launch_bounds__(256) void k_fill_path_slots(const uint2 *pairs, uint32_t n, uint32_t *table) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) table[pairs[i].x] = pairs[i].y;
 }
 
 // ---- surface reconstruction ------------------------------------------------------------------------
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
         const unsigned long long key = A.cur.best[i];
         if (key != ~0ull && __uint_as_float((uint32_t)(key >> 32)) < ht) {
             const uint32_t kr = (uint32_t)key;
-            const TriDev &T = S.ltris[(A.recs[kr >> 2].y & LEAF_SLOT_MASK) + (kr & 3u)];
+            const TriDev &T = S.ltris[S.path_slot[(kr >> 2) ^ near_upper_levels(rd)] + (kr & 3u)];
             hit_tri(T, S.tri_eps, ro, rd, ht);   // the winner's exact t (the key folds -0 onto +0)
             hf = T.face;
             A.cur.ht[i] = ht;

@@ -68,6 +68,24 @@ def test_config2_res4_1920x1080():
     check_against_oracle(flat)
 
 
+def test_duplicate_faces_first_visited_wins():
+    """Every face of the mesh twice, in a seeded random order, the copies with another material: a ray then finds
+    two faces at exactly the same distance, often listed in different leaves (leaves keep four faces and drop the
+    rest). The shader keeps the face it tests first (strict `hitInfo.t < tMin`, js/8-kd_tree.js:948-949): hit ids,
+    colours and ray counts must still equal the oracle's, which walks the cells in the shader's order."""
+    flat = make_flat("bun_zipper_res4.ply", 320, 240, depth=3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    n = len(flat.faces)
+    order = np.random.RandomState(7).permutation(2 * n)
+    faces = np.concatenate([flat.faces, flat.faces])[order]
+    mats = np.concatenate([flat.face_mat, np.tile(np.array([[0, 1]], flat.face_mat.dtype), (n, 1))])[order]
+    flat.faces, flat.face_mat = np.ascontiguousarray(faces), np.ascontiguousarray(mats)
+    _, _, (_, _, ids), _ = check_against_oracle(flat)
+    mesh_ids = ids[ids >= len(flat.prims)] - len(flat.prims)
+    assert len(mesh_ids) > 1000
+    copies = (order[mesh_ids] >= n).mean()
+    assert 0.2 < copies < 0.8, copies      # both the originals and the copies win somewhere
+
+
 def test_brute_force_triangles_match():
     flat = make_flat("bun_zipper_res4.ply", 160, 120, depth=2, use_kd_tree=0)
     check_against_oracle(flat)
