@@ -71,6 +71,7 @@ struct rt_ctx {
     hipStream_t stream = nullptr;                // scene uploads, tone, present (= the first part's stream)
     hipEvent_t ev_misc[2]{};                     // tone begin / end
     int n_cus = 256;
+    int walk_waves_per_cu = RT_WALK_WAVES_PER_CU;
     int n_parts = 1;
     Part parts[MAX_PARTS];
     // scene (host copies)
@@ -379,6 +380,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     }
     np = std::max(1, std::min({np, MAX_PARTS, (int)std::max<uint32_t>(my_tiles, 1u)}));
     ctx->n_parts = np;
+    if (const char *env = getenv("RT_WALK_WAVES")) ctx->walk_waves_per_cu = std::max(1, std::min(atoi(env), 32));   // tuning hook
     for (int p = 0; p < np; p++) {
         Part &P = ctx->parts[p];
         if ((e = hipStreamCreate(&P.stream)) != hipSuccess) return bail("hipStreamCreate", e);
@@ -619,7 +621,7 @@ static int launch_step(rt_ctx *ctx, Part &P, int k) {
     }
     const dim3 grid((n + BLOCK - 1) / BLOCK), grid_prev((B.n_rays + BLOCK - 1) / BLOCK);
     // persistent traversal waves: one 64-lane workgroup each (4 KB of LDS for the short stacks)
-    const dim3 walk_grid((unsigned)ctx->n_cus * (unsigned)RT_WALK_WAVES_PER_CU);
+    const dim3 walk_grid((unsigned)ctx->n_cus * (unsigned)ctx->walk_waves_per_cu);
     const dim3 test_grid((unsigned)ctx->n_cus * 32u);   // grid-stride over the records
     const bool any_walk = Wk.job[0].enabled || Wk.job[1].enabled;
     hipEvent_t *ev = P.ev[k];
@@ -763,6 +765,10 @@ int rt_trace(rt_ctx *ctx) {
 #ifdef RT_WALK_STATS
             fprintf(stderr, "walk stats part %d level %d: closest iters %llu visits %llu | shadow iters %llu visits %llu\n", p, l,
                     hc.walk_iters[0], hc.walk_visits[0], hc.walk_iters[1], hc.walk_visits[1]);
+            for (int j = 0; j < 2; j++)   // 100 MHz ticks -> microseconds
+                fprintf(stderr, "    %s: span %.1f us, mean wave lifetime %.1f us\n", j ? "shadow" : "closest",
+                        (double)(hc.walk_t1[j] - ~hc.walk_t0[j]) * 0.01,
+                        (double)hc.walk_tsum[j] * 0.01 / ((double)ctx->n_cus * ctx->walk_waves_per_cu));
 #endif
         }
         const int steps = P.levels_run ? P.levels_run + 1 : 0;

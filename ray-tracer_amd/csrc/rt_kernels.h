@@ -265,10 +265,11 @@ constexpr int REFILL_CHUNK = RT_REFILL_CHUNK;                    // rays a wave 
 #endif
 constexpr int REC_CHUNK = RT_REC_CHUNK;                      // records a wave reserves per atomic
 constexpr int SHORT_STACK = RT_SHORT_STACK;          // power of two
+constexpr int MAIL_SLOTS = 32;                       // stretches that change hands in one exchange of a wave
 constexpr uint32_t REC_FILLER = 0u;   // a record's second word is count << 27 | first slot; count 0 = filler
 
 template <bool ANY>
-__device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, uint2 *stack, const uint32_t lane) {
+__device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, uint2 *stack, uint4 *mail, const uint32_t lane) {
     const KdNodeDev *__restrict__ nodes = S.nodes;
     const uint32_t total = ANY ? min(J.cnt->shq_count, J.q_cap) : J.cnt->kdq_count;
     uint32_t *head = ANY ? &J.cnt->shq_head : &J.cnt->kdq_head;
@@ -303,12 +304,61 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
         if (n_idle >= (uint32_t)REFILL_MIN_IDLE) {
             if (!UNIFORM(more)) {
                 if (n_idle == (uint32_t)WAVE) break;
+#ifndef RT_NO_STEAL
+                // ---- the global queue is dry: idle lanes take over the far end of their neighbours' rays. A walking
+                //      lane hands the OLDEST entry of its stack - the subtree that covers the last stretch of its ray -
+                //      to an idle lane and ends its own ray where that stretch begins. Every entry a lane pushes is
+                //      popped and walked sooner or later (a walk only ends early on a NaN plane distance, which needs
+                //      a zero direction component: such rays do not give), so the same leaves are visited; only who
+                //      visits them changes, and the order of the triangle tests does not matter (see k_tri_test).
+                //      If the ring had dropped entries, the taker inherits the old end of the ray and restarts at the
+                //      root after its stretch, exactly as the giver would have.
+                const bool can_give = info != 0u && sp_top != sp_lo && dx != 0.0f && dy != 0.0f && dz != 0.0f &&
+                                      dx == dx && dy == dy && dz == dz;
+                const unsigned long long givers = __builtin_amdgcn_ballot_w64(can_give);
+                if (givers != 0ull) {
+                    if (can_give) {
+                        const uint32_t g = RANK_IN(givers);
+                        if (g < min(n_idle, (uint32_t)MAIL_SLOTS)) {
+                            const uint2 bot = stack[((uint32_t)sp_lo & (SHORT_STACK - 1)) * WAVE];
+                            // an entry's stretch begins where the entry above it ends, the newest one's at the lane's tmax
+                            const float start = (sp_top - sp_lo > 1)
+                                ? __uint_as_float(stack[((uint32_t)(sp_lo + 1) & (SHORT_STACK - 1)) * WAVE].y) : tmax;
+                            mail[g] = make_uint4(bot.x, __float_as_uint(start), bot.y, ref);
+                            mail[MAIL_SLOTS + g] = make_uint4(__float_as_uint(maxDist), __float_as_uint(ox), __float_as_uint(oy), __float_as_uint(oz));
+                            mail[2 * MAIL_SLOTS + g] = make_uint4(__float_as_uint(dx), __float_as_uint(dy), __float_as_uint(dz), 0u);
+                            sp_lo += 1;
+                            maxDist = start;
+                        }
+                    }
+                    __syncthreads();   // one wave per workgroup: orders the mailbox writes before the reads
+                    const uint32_t taker = RANK_IN(idle);
+                    if (info == 0u && taker < min(COUNT_OF(givers), (uint32_t)MAIL_SLOTS)) {
+                        const uint4 m0 = mail[taker], m1 = mail[MAIL_SLOTS + taker], m2 = mail[2 * MAIL_SLOTS + taker];
+                        ref = m0.w;
+                        maxDist = __uint_as_float(m1.x);
+                        ox = __uint_as_float(m1.y); oy = __uint_as_float(m1.z); oz = __uint_as_float(m1.w);
+                        dx = __uint_as_float(m2.x); dy = __uint_as_float(m2.y); dz = __uint_as_float(m2.z);
+                        // the taker stands on a pretended empty leaf that ends where the stretch begins, with the
+                        // stretch as the only entry of its stack: the tree action below pops it and fetches the node
+                        tmin = tmax = __uint_as_float(m0.y);
+                        stack[0] = make_uint2(m0.x, m0.z);
+                        sp_lo = 0;
+                        sp_top = 1;
+                        info = 0x80000000u;
+                        split = 0.0f;
+                    }
+                    __syncthreads();
+                }
+#endif
             } else {
                 const uint32_t rank = RANK_IN(idle);
                 const uint32_t left = chunk_end - chunk_pos;
                 uint32_t q;
                 if (left < n_idle) {
                     // the rays left in the old chunk are taken first, the rest comes from a new chunk
+                    // (a device-scope load of the cursor before the atomic, to spare the failing atomics at the end of
+                    // the queue, measured twice as slow for the whole walk)
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(head, (uint32_t)REFILL_CHUNK);
                     base = UNIFORM(base);
@@ -434,9 +484,10 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
 
 __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
     __shared__ uint2 s_stack[SHORT_STACK * WAVE];
+    __shared__ uint4 s_mail[3 * MAIL_SLOTS];      // stretches handed from walking lanes to idle ones
     const uint32_t lane = threadIdx.x;
-    if (A.job[0].enabled) walk_job<true>(A.S, A.job[0], s_stack + lane, lane);
-    if (A.job[1].enabled) walk_job<false>(A.S, A.job[1], s_stack + lane, lane);
+    if (A.job[0].enabled) walk_job<true>(A.S, A.job[0], s_stack + lane, s_mail, lane);
+    if (A.job[1].enabled) walk_job<false>(A.S, A.job[1], s_stack + lane, s_mail, lane);
 }
 
 // ---- triangle tests over the records of a walk -------------------------------------------------------------
@@ -459,22 +510,21 @@ __device__ __forceinline__ void test_job(const SceneDev &S, const WalkJob &J) {
         }
         V3 ro, rd;
         load_ray(J.rays, rec.x, ro, rd);
-        // visit rank of this leaf for this ray (see path_code) and the face's position in the leaf
-        const uint32_t order = ANY ? 0u : ((S.ltris[first].code ^ near_upper_levels(rd)) << 2);
         unsigned long long key = ~0ull;
         for (uint32_t k = 0; k < count; k++) {
             float t;
             if (hit_tri(S.ltris[first + k], S.tri_eps, ro, rd, t)) {
                 // t >= 0 here, so the float bits order like the values; -0 is folded onto +0
                 const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);
-                const unsigned long long kk = ((unsigned long long)tb << 32) | (unsigned long long)(order | k);
+                const unsigned long long kk = ((unsigned long long)tb << 32) | (unsigned long long)k;
                 key = kk < key ? kk : key;
                 if (ANY) break;
             }
         }
-        if (key != ~0ull) {
+        if (key != ~0ull) {   // few records hit: the rest of the key is made only here
             if (ANY) atomicOr(&J.shadow[id >> 5], 1u << (id & 31u));
-            else atomicMin(&J.best[rec.x], key);
+            // low word: visit rank of this leaf for this ray (see path_code), then the face's position in the leaf
+            else atomicMin(&J.best[rec.x], key | (unsigned long long)((S.ltris[first].code ^ near_upper_levels(rd)) << 2));
         }
     }
 }
