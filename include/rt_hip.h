@@ -160,6 +160,16 @@ int rt_export_kdtree_reference(rt_ctx *ctx, uint32_t *nodes, int32_t *leaves, do
 
 /* ---- frame: replaces the tracer draw call (js/8-kd_tree.js:2550-2555) -------------------- */
 int rt_trace(rt_ctx *ctx);
+/* The same frame in two halves, for callers that overlap work with the trace. No counterpart in the reference
+ * (its update() blocks in gl.readPixels, js/8-kd_tree.js:2558).
+ * rt_trace_begin queues the whole frame on the context's stream and returns without waiting for the device; the
+ * entry points that queue device work (rt_tone_partial, rt_present, rt_assemble_shards) may be called right after it
+ * and run behind the trace. rt_trace_end waits for the trace and checks that every buffer was large enough (they are
+ * sized from the previous frames). It returns 0 when the frame is complete, 1 when buffers had to grow and the frame
+ * was traced again - it is complete now, but whatever was derived from the first attempt (tone sums, presented or
+ * gathered pixels) must be redone - and a negative value on failure. rt_trace = rt_trace_begin + rt_trace_end. */
+int rt_trace_begin(rt_ctx *ctx);
+int rt_trace_end(rt_ctx *ctx);
 /* float colour before clamping, 3 floats per pixel, width*S x height*S, bottom-up rows.
  * Pixels outside this context's shard are left untouched. */
 int rt_read_float(rt_ctx *ctx, float *rgb);

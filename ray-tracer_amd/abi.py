@@ -132,6 +132,8 @@ def lib():
         L.rt_kdtree_counts.argtypes = [vp, i64p, i64p]
         L.rt_export_kdtree_reference.argtypes = [vp, vp, vp, vp]
         L.rt_trace.argtypes = [vp]
+        L.rt_trace_begin.argtypes = [vp]
+        L.rt_trace_end.argtypes = [vp]
         L.rt_read_float.argtypes = [vp, vp]
         L.rt_read_rgba8.argtypes = [vp, vp]
         L.rt_read_hit_ids.argtypes = [vp, vp]
@@ -228,6 +230,17 @@ class RayTracerHIP:
 
     def trace(self):
         self._ck(self.L.rt_trace(self.ctx), "rt_trace")
+
+    def traceBegin(self):
+        self._ck(self.L.rt_trace_begin(self.ctx), "rt_trace_begin")
+
+    def traceEnd(self):
+        """True when the frame had to be traced again with larger buffers (work queued behind the first attempt
+        must be redone)."""
+        rc = self.L.rt_trace_end(self.ctx)
+        if rc < 0:
+            self._ck(rc, "rt_trace_end")
+        return rc == 1
 
     def readFloat(self):
         out = np.zeros((self.H, self.W, 3), np.float32)

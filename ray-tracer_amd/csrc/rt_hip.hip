@@ -43,7 +43,9 @@ constexpr int MAX_PARTS = 8;
 struct Part {
     hipStream_t stream = nullptr;
     hipEvent_t ev[MAX_STEPS][N_STAGES + 1]{};    // stage boundaries of every step
-    hipEvent_t ev_begin = nullptr, ev_comp = nullptr, ev_end = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_comp = nullptr, ev_end = nullptr, ev_counts = nullptr;
+    uint32_t want[MAX_LEVELS]{};                 // capacity the next frame gives level l (0 = not known yet)
+    size_t want_recs[2] = {0, 0};
     Level lv[MAX_LEVELS];
     LevelCounters *d_counts = nullptr;           // one block of counters per level
     LevelCounters *h_counts = nullptr;           // pinned host copy
@@ -59,8 +61,6 @@ struct Part {
     FrameGeom g{};
     uint32_t n0 = 0;                             // level-0 entries = tiles of this part * 64
     int levels_run = 0;
-    int pending = -1;                            // step launched and not yet collected, -1 = none
-    int attempt = 0;
 };
 
 }  // namespace
@@ -108,6 +108,7 @@ struct rt_ctx {
     unsigned long long *d_part_cnt = nullptr, *d_tone_cnt = nullptr;
     double Lbar = 0.0, sf = 0.0;
     bool traced = false;
+    bool in_flight = false;                      // rt_trace_begin without its rt_trace_end
     bool host_only = false;
     rt_stats st{};
 };
@@ -387,7 +388,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
         for (auto &row : P.ev)
             for (auto &ev : row)
                 if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-        for (hipEvent_t *ev : {&P.ev_begin, &P.ev_comp, &P.ev_end})
+        for (hipEvent_t *ev : {&P.ev_begin, &P.ev_comp, &P.ev_end, &P.ev_counts})
             if ((e = hipEventCreate(ev)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipMalloc((void **)&P.d_counts, MAX_LEVELS * sizeof(LevelCounters))) != hipSuccess) return bail("hipMalloc", e);
         if ((e = hipMemset(P.d_counts, 0, MAX_LEVELS * sizeof(LevelCounters))) != hipSuccess) return bail("hipMemset", e);
@@ -442,7 +443,7 @@ void rt_destroy(rt_ctx *ctx) {
         for (auto &row : P.ev)
             for (auto &ev : row)
                 if (ev) (void)hipEventDestroy(ev);
-        for (hipEvent_t ev : {P.ev_begin, P.ev_comp, P.ev_end})
+        for (hipEvent_t ev : {P.ev_begin, P.ev_comp, P.ev_end, P.ev_counts})
             if (ev) (void)hipEventDestroy(ev);
         if (P.stream) (void)hipStreamDestroy(P.stream);
     }
@@ -555,60 +556,49 @@ int rt_export_kdtree_reference(rt_ctx *ctx, uint32_t *nodes, int32_t *leaves, do
     return 0;
 }
 
-// launches pipeline step k of one part and the copy of the counters it changes to the host
+// queues pipeline step k of one part. Nothing here waits for the device: every kernel reads the number of rays of its
+// level from the counters the previous step left in device memory and is launched over the level's capacity.
 static int launch_step(rt_ctx *ctx, Part &P, int k) {
     const int D = ctx->cfg.max_depth;
     const SceneDev &sh = ctx->sh;
     const bool walk = sh.render_triangles && sh.use_kd;
-    const bool have_cur = k < D && P.n_rays[k] > 0;   // level k exists: its closest-hit half runs in this step
-    const bool have_prev = k >= 1;                    // level k-1 exists: its shadow half runs in this step
+    const bool have_cur = k < D;      // level k exists: its closest-hit half runs in this step
+    const bool have_prev = k >= 1;    // level k-1 exists: its shadow half runs in this step
     const bool last = (k == D - 1);
-    const uint32_t n = have_cur ? P.n_rays[k] : 0;
     hipStream_t s = P.stream;
-    if (have_cur) {
-        if (!last) {
-            uint64_t want = std::min<uint64_t>(2ull * n, 0x7fffff00ull);
-            if (ensure_level(ctx, P, k + 1, (uint32_t)want)) return -1;
-        }
-        if (ensure_queues(ctx, P, k, n, (uint32_t)sh.n_lights)) return -1;
-        if (walk && P.cap_recs[0] == 0 && ensure(ctx, P.d_recs[0], P.cap_recs[0], std::max<size_t>((size_t)8 << 20, (size_t)n * 8))) return -1;
-        if (walk && P.cap_recs[1] == 0 && ensure(ctx, P.d_recs[1], P.cap_recs[1], std::max<size_t>((size_t)8 << 20, (size_t)n * 8))) return -1;
-    }
+    auto level_args = [&](int l) {
+        LevelArgs A{};
+        A.S = ctx->sh;
+        A.cur = P.lv[l].b;
+        if (l < D - 1) { A.nxt = P.lv[l + 1].b; A.nxt_cap = P.lv[l + 1].cap; }
+        A.shq = P.shq[l & 1];
+        A.shq_cap = P.cap_shq[l & 1];
+        A.kdq = P.d_kdq;
+        A.cnt = P.d_counts + l;
+        A.n_src = l > 0 ? &P.d_counts[l - 1].next_count : nullptr;
+        A.n_rays = l > 0 ? P.lv[l].cap : P.n0;
+        A.hit_ids = ctx->d_hit;
+        A.g = P.g;
+        A.level = l;
+        A.last_level = (l == D - 1) ? 1 : 0;
+        return A;
+    };
     LevelArgs A{}, B{};
     WalkArgs Wk{};
     Wk.S = ctx->sh;
     if (have_cur) {
-        A.S = ctx->sh;
-        A.cur = P.lv[k].b;
-        if (!last) { A.nxt = P.lv[k + 1].b; A.nxt_cap = P.lv[k + 1].cap; }
-        A.shq = P.shq[k & 1];
-        A.shq_cap = P.cap_shq[k & 1];
-        A.kdq = P.d_kdq;
-        A.recs = P.d_recs[0];
-        A.rec_cap = (uint32_t)std::min<size_t>(P.cap_recs[0], 0x3fffff00u);
-        A.cnt = P.d_counts + k;
-        A.n_rays = n;
-        A.hit_ids = ctx->d_hit;
-        A.g = P.g;
-        A.level = k;
-        A.last_level = last ? 1 : 0;
+        A = level_args(k);
         WalkJob &J = Wk.job[1];
         J.rays = P.lv[k].b.ray;
         J.kdq = P.d_kdq;
         J.best = P.lv[k].b.best;
         J.cnt = P.d_counts + k;
         J.recs = P.d_recs[0];
-        J.rec_cap = A.rec_cap;
+        J.rec_cap = (uint32_t)std::min<size_t>(P.cap_recs[0], 0x3fffff00u);
         J.enabled = walk ? 1u : 0u;
     }
     if (have_prev) {
-        B.S = ctx->sh;
-        B.cur = P.lv[k - 1].b;
-        B.cnt = P.d_counts + (k - 1);
-        B.n_rays = P.n_rays[k - 1];
-        B.g = P.g;
-        B.level = k - 1;
-        B.last_level = (k - 1 == D - 1) ? 1 : 0;
+        B = level_args(k - 1);
         WalkJob &J = Wk.job[0];
         J.rays = P.shq[(k - 1) & 1].ray;
         J.shq_id = P.shq[(k - 1) & 1].id;
@@ -619,8 +609,9 @@ static int launch_step(rt_ctx *ctx, Part &P, int k) {
         J.q_cap = P.cap_shq[(k - 1) & 1];
         J.enabled = walk ? 1u : 0u;
     }
-    const dim3 grid((n + BLOCK - 1) / BLOCK), grid_prev((B.n_rays + BLOCK - 1) / BLOCK);
-    // persistent traversal waves: one 64-lane workgroup each (4 KB of LDS for the short stacks)
+    (void)last;
+    const dim3 grid((A.n_rays + BLOCK - 1) / BLOCK), grid_prev((B.n_rays + BLOCK - 1) / BLOCK);
+    // persistent traversal waves: one 64-lane workgroup each (LDS: short stacks + mailbox)
     const dim3 walk_grid((unsigned)ctx->n_cus * (unsigned)ctx->walk_waves_per_cu);
     const dim3 test_grid((unsigned)ctx->n_cus * 32u);   // grid-stride over the records
     const bool any_walk = Wk.job[0].enabled || Wk.job[1].enabled;
@@ -637,105 +628,101 @@ static int launch_step(rt_ctx *ctx, Part &P, int k) {
     if (have_cur) hipLaunchKernelGGL(k_shade_a, grid, dim3(BLOCK), 0, s, A);
     HIPCK(hipGetLastError());
     HIPCK(hipEventRecord(ev[5], s));
-    const int first = have_prev ? k - 1 : k, count = (have_prev ? 1 : 0) + (k < D ? 1 : 0);
-    HIPCK(hipMemcpyAsync(P.h_counts + first, P.d_counts + first, (size_t)count * sizeof(LevelCounters), hipMemcpyDeviceToHost, s));
-    P.pending = k;
     return 0;
 }
 
-// waits for the pending step of a part. One host round trip per step and part: the number of children sizes the
-// next level, and a walk that ran out of record space wrote nothing past the capacity, so the step is repeated with
-// a larger buffer (every stage of a step starts from the state the previous step left: the closest-hit half resets
-// its own counters' level, the shadow half only ever ORs bits in). Returns 1 when the step has to be launched again.
-static int collect_step(rt_ctx *ctx, Part &P) {
-    const int k = P.pending;
-    const int D = ctx->cfg.max_depth;
-    const bool walk = ctx->sh.render_triangles && ctx->sh.use_kd;
-    const bool have_cur = k < D && P.n_rays[k] > 0;
-    HIPCK(hipStreamSynchronize(P.stream));
-    P.pending = -1;
-    const size_t need0 = have_cur ? P.h_counts[k].rec_count[0] : 0;
-    const size_t need1 = k >= 1 ? P.h_counts[k - 1].rec_count[1] : 0;
-    const bool over0 = walk && need0 > std::min<size_t>(P.cap_recs[0], 0x3fffff00u);
-    const bool over1 = walk && need1 > std::min<size_t>(P.cap_recs[1], 0x3fffff00u);
-    if (over0 || over1) {
-        if (P.attempt >= 3 || need0 > 0x3fffff00u || need1 > 0x3fffff00u) return fail(ctx, "rt_trace: leaf record buffer cannot hold one level");
-        if (over0 && ensure(ctx, P.d_recs[0], P.cap_recs[0], need0 + need0 / 4)) return -1;
-        if (over1 && ensure(ctx, P.d_recs[1], P.cap_recs[1], need1 + need1 / 4)) return -1;
-        if (have_cur) HIPCK(hipMemsetAsync(P.d_counts + k, 0, sizeof(LevelCounters), P.stream));
-        if (k >= 1) {   // the previous level keeps its queue length; its queue cursor and shadow record count start over
-            LevelCounters *c = P.d_counts + (k - 1);
-            HIPCK(hipMemsetAsync(&c->shq_head, 0, sizeof(uint32_t), P.stream));
-            HIPCK(hipMemsetAsync(&c->rec_count[1], 0, sizeof(uint32_t), P.stream));
-        }
-        P.attempt++;
-        return 1;
-    }
-    P.attempt = 0;
-    P.rec_total[0] += need0;
-    P.rec_total[1] += need1;
-    if (have_cur) {
-        if (k < D - 1) P.n_rays[k + 1] = std::min(P.h_counts[k].next_count, P.lv[k + 1].cap);
-        P.levels_run = k + 1;
-    }
-    return 0;
-}
-
-int rt_trace(rt_ctx *ctx) {
-    if (!ctx) return -1;
-    if (ctx->host_only) return fail(ctx, "rt_trace: host-only context (created with device = -1)");
-    HIPCK(hipSetDevice(ctx->cfg.device));
-    if (ctx->scene_dirty && upload_scene(ctx)) return -1;
+// Queues one whole frame of a part: D+1 pipeline steps, the bottom-up colour fold, the resolve, and one copy of all
+// counters to the host. The buffers are sized from what earlier frames needed (first frame: level 0's size for every
+// level); finish_part checks afterwards that nothing was dropped.
+static int enqueue_part(rt_ctx *ctx, Part &P) {
     const int D = ctx->cfg.max_depth;
     const SceneDev &sh = ctx->sh;
-    const int NP = ctx->n_parts;
-    // step 0 of every part goes out first; from then on a part's next step is launched as soon as its counters
-    // are back, while the other parts keep the GPU busy
-    for (int p = 0; p < NP; p++) {
-        Part &P = ctx->parts[p];
-        P.levels_run = 0;
-        P.pending = -1;
-        P.attempt = 0;
-        P.rec_total[0] = P.rec_total[1] = 0;
-        memset(P.n_rays, 0, sizeof P.n_rays);
-        P.n_rays[0] = P.n0;
-        HIPCK(hipMemsetAsync(P.d_counts, 0, MAX_LEVELS * sizeof(LevelCounters), P.stream));
-        HIPCK(hipEventRecord(P.ev_begin, P.stream));
-        if (P.n0 == 0) continue;
-        if (ensure_level(ctx, P, 0, P.n0)) return -1;
-        if (launch_step(ctx, P, 0)) return -1;
-    }
-    for (bool busy = true; busy;) {
-        busy = false;
-        for (int p = 0; p < NP; p++) {
-            Part &P = ctx->parts[p];
-            if (P.pending < 0) continue;
-            const int k = P.pending;
-            const int again = collect_step(ctx, P);
-            if (again < 0) return -1;
-            // step k+1 exists while level k existed: it finishes that level's shadow rays
-            const int next = again ? k : k + 1;
-            if (next <= D && (next == k || P.levels_run == k + 1)) {
-                if (launch_step(ctx, P, next)) return -1;
-                busy = true;
-            }
-        }
-    }
-    for (int p = 0; p < NP; p++) {
-        Part &P = ctx->parts[p];
-        hipStream_t s = P.stream;
+    const bool walk = sh.render_triangles && sh.use_kd;
+    hipStream_t s = P.stream;
+    HIPCK(hipMemsetAsync(P.d_counts, 0, MAX_LEVELS * sizeof(LevelCounters), s));
+    HIPCK(hipEventRecord(P.ev_begin, s));
+    if (P.n0 == 0) {
         HIPCK(hipEventRecord(P.ev_comp, s));
-        for (int l = P.levels_run - 2; l >= 0; l--) {
-            if (P.n_rays[l + 1] == 0) continue;
-            hipLaunchKernelGGL(k_composite, dim3((P.n_rays[l] + 255) / 256), dim3(256), 0, s, P.lv[l].b, P.lv[l + 1].b, P.n_rays[l]);
-        }
-        if (P.n0) hipLaunchKernelGGL(k_resolve, dim3((P.n0 + 255) / 256), dim3(256), 0, s, P.lv[0].b, P.n0, P.g, ctx->d_fb,
-                                     ctx->d_rgba, ctx->d_compact);
-        HIPCK(hipGetLastError());
         HIPCK(hipEventRecord(P.ev_end, s));
+        return 0;
     }
-    for (int p = 0; p < NP; p++) HIPCK(hipStreamSynchronize(ctx->parts[p].stream));
+    if (ensure_level(ctx, P, 0, P.n0)) return -1;
+    for (int l = 1; l < D; l++) {
+        if (P.want[l] == 0) P.want[l] = P.n0;
+        if (ensure_level(ctx, P, l, P.want[l])) return -1;
+    }
+    for (int l = 0; l < D; l++)
+        if (ensure_queues(ctx, P, l, P.lv[l].cap, (uint32_t)sh.n_lights)) return -1;
+    if (walk)
+        for (int j = 0; j < 2; j++) {
+            if (P.want_recs[j] == 0) P.want_recs[j] = std::max<size_t>((size_t)8 << 20, (size_t)P.n0 * 8);
+            if (ensure(ctx, P.d_recs[j], P.cap_recs[j], P.want_recs[j])) return -1;
+        }
+    for (int k = 0; k <= D; k++)
+        if (launch_step(ctx, P, k)) return -1;
+    HIPCK(hipEventRecord(P.ev_comp, s));
+    for (int l = D - 2; l >= 0; l--) {
+        const uint32_t bound = l > 0 ? P.lv[l].cap : P.n0;
+        hipLaunchKernelGGL(k_composite, dim3((bound + 255) / 256), dim3(256), 0, s, P.lv[l].b, P.lv[l + 1].b,
+                           l > 0 ? &P.d_counts[l - 1].next_count : (const uint32_t *)nullptr, bound);
+    }
+    hipLaunchKernelGGL(k_resolve, dim3((P.n0 + 255) / 256), dim3(256), 0, s, P.lv[0].b, P.n0, P.g, ctx->d_fb, ctx->d_rgba,
+                       ctx->d_compact);
+    HIPCK(hipGetLastError());
+    HIPCK(hipEventRecord(P.ev_end, s));
+    HIPCK(hipMemcpyAsync(P.h_counts, P.d_counts, (size_t)D * sizeof(LevelCounters), hipMemcpyDeviceToHost, s));
+    HIPCK(hipEventRecord(P.ev_counts, s));
+    return 0;
+}
 
+// Waits for the part's frame and checks the counters: children beyond a level's capacity were dropped, leaf records
+// beyond the buffer were not written. Either makes the frame wrong, so the buffers are grown to what the counters ask
+// for and 1 is returned: the caller queues the frame again. (Counts below a level that overflowed are too low; a
+// later attempt sees them.)
+static int finish_part(rt_ctx *ctx, Part &P) {
+    const int D = ctx->cfg.max_depth;
+    const bool walk = ctx->sh.render_triangles && ctx->sh.use_kd;
+    HIPCK(hipEventSynchronize(P.ev_counts));
+    memset(P.n_rays, 0, sizeof P.n_rays);
+    P.levels_run = 0;
+    P.rec_total[0] = P.rec_total[1] = 0;
+    if (P.n0 == 0) return 0;
+    bool again = false;
+    P.n_rays[0] = P.n0;
+    size_t need_recs[2] = {0, 0};
+    for (int l = 0; l < D; l++) {
+        if (P.n_rays[l] == 0) break;
+        P.levels_run = l + 1;
+        const LevelCounters &hc = P.h_counts[l];
+        if (l + 1 < D) {
+            if (hc.next_count > P.lv[l + 1].cap) {
+                if (hc.next_count > 0x7fffff00u) return fail(ctx, "rt_trace: a ray-tree level exceeds 2^31 rays");
+                // the deeper levels usually grow by the same factor
+                const double f = (double)hc.next_count / (double)std::max<uint32_t>(P.lv[l + 1].cap, 1u);
+                for (int m = l + 1; m < D; m++) {
+                    const double w = (m == l + 1 ? (double)hc.next_count : (double)P.lv[m].cap * f) * 1.25;
+                    P.want[m] = (uint32_t)std::min<double>(std::max<double>(w, (double)P.want[m]), (double)0x7fffff00u);
+                }
+                again = true;
+            }
+            P.n_rays[l + 1] = std::min(hc.next_count, P.lv[l + 1].cap);
+        }
+        for (int j = 0; j < 2; j++) need_recs[j] = std::max<size_t>(need_recs[j], hc.rec_count[j]);
+        P.rec_total[0] += hc.rec_count[0];
+        P.rec_total[1] += hc.rec_count[1];
+    }
+    for (int j = 0; j < 2 && walk; j++)
+        if (need_recs[j] > std::min<size_t>(P.cap_recs[j], 0x3fffff00u)) {
+            if (need_recs[j] > 0x3fffff00u) return fail(ctx, "rt_trace: leaf record buffer cannot hold one level");
+            P.want_recs[j] = need_recs[j] + need_recs[j] / 4;
+            again = true;
+        }
+    return again ? 1 : 0;
+}
+
+static int collect_stats(rt_ctx *ctx) {
+    const SceneDev &sh = ctx->sh;
+    const int NP = ctx->n_parts, D = ctx->cfg.max_depth;
     rt_stats &st = ctx->st;
     const double keep_build = st.kd_build_ms, keep_upload = st.kd_upload_ms, keep_tone = st.tone_ms;
     memset(&st, 0, sizeof st);
@@ -771,8 +758,8 @@ int rt_trace(rt_ctx *ctx) {
                         (double)hc.walk_tsum[j] * 0.01 / ((double)ctx->n_cus * ctx->walk_waves_per_cu));
 #endif
         }
-        const int steps = P.levels_run ? P.levels_run + 1 : 0;
-        for (int k = 0; k < steps && k < MAX_STEPS; k++) {
+        if (P.n0 == 0) continue;
+        for (int k = 0; k <= D && k < MAX_STEPS; k++) {
             float ms = 0;
             for (int j = 0; j < N_STAGES; j++) {
                 HIPCK(hipEventElapsedTime(&ms, P.ev[k][j], P.ev[k][j + 1]));
@@ -789,8 +776,53 @@ int rt_trace(rt_ctx *ctx) {
         st.composite_ms += ms;
     }
     for (int l = 0; l < MAX_LEVELS; l++) st.rays_total += st.rays_per_level[l];
+    return 0;
+}
+
+int rt_trace_begin(rt_ctx *ctx) {
+    if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_trace: host-only context (created with device = -1)");
+    if (ctx->in_flight) return fail(ctx, "rt_trace_begin: the previous frame was not finished with rt_trace_end");
+    HIPCK(hipSetDevice(ctx->cfg.device));
+    if (ctx->scene_dirty && upload_scene(ctx)) return -1;
+    for (int p = 0; p < ctx->n_parts; p++)
+        if (enqueue_part(ctx, ctx->parts[p])) return -1;
+    // everything queued on the main stream after this call (tone, present, a caller's exchange) follows the trace
+    for (int p = 1; p < ctx->n_parts; p++) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->parts[p].ev_end, 0));
+    ctx->in_flight = true;
     ctx->traced = true;
     return 0;
+}
+
+int rt_trace_end(rt_ctx *ctx) {
+    if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_trace: host-only context (created with device = -1)");
+    if (!ctx->in_flight) return fail(ctx, "rt_trace_end: no frame in flight");
+    HIPCK(hipSetDevice(ctx->cfg.device));
+    ctx->in_flight = false;
+    int reruns = 0;
+    for (;;) {
+        bool again = false;
+        for (int p = 0; p < ctx->n_parts; p++) {
+            const int r = finish_part(ctx, ctx->parts[p]);
+            if (r < 0) return -1;
+            again = again || r == 1;
+        }
+        if (!again) break;
+        if (++reruns > 2 * MAX_LEVELS + 4) return fail(ctx, "rt_trace: buffers still too small after repeated growth");
+        // whatever was queued behind the first attempt ran on a frame with dropped rays: drain it, then trace again
+        HIPCK(hipStreamSynchronize(ctx->stream));
+        for (int p = 0; p < ctx->n_parts; p++)
+            if (enqueue_part(ctx, ctx->parts[p])) return -1;
+        for (int p = 1; p < ctx->n_parts; p++) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->parts[p].ev_end, 0));
+    }
+    if (collect_stats(ctx)) return -1;
+    return reruns ? 1 : 0;
+}
+
+int rt_trace(rt_ctx *ctx) {
+    if (rt_trace_begin(ctx)) return -1;
+    return rt_trace_end(ctx) < 0 ? -1 : 0;
 }
 
 int rt_read_float(rt_ctx *ctx, float *rgb) {

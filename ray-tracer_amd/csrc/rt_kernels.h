@@ -82,7 +82,10 @@ struct LevelArgs {
     uint4 *kdq;             // closest-hit traversal queue: (ray index, root-box entry distance, exit distance, -)
     const uint2 *recs;      // triangle records of the closest walk (k_shade_a resolves the winner)
     LevelCounters *cnt;
-    uint32_t n_rays, nxt_cap, shq_cap, rec_cap;
+    const uint32_t *n_src;  // levels below 0: where the parent level counted its children (read on the device, so that
+                            // the host can queue a whole frame without waiting for any count); null = n_rays is exact
+    uint32_t n_rays;        // entries of this level, or with n_src the capacity that bounds the count
+    uint32_t nxt_cap, shq_cap, rec_cap;
     int32_t *hit_ids;       // level 0 only, full frame
     FrameGeom g;
     int32_t level, last_level;
@@ -103,6 +106,11 @@ __device__ __forceinline__ V3 mix3(V3 a, V3 b, float t) {
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// number of rays of the level a kernel works on (wave-uniform, scalar load)
+__device__ __forceinline__ uint32_t level_rays(const uint32_t *n_src, uint32_t bound) {
+    return n_src ? min(*n_src, bound) : bound;
+}
 
 __device__ __forceinline__ void load_ray(const float4 *ray, uint32_t i, V3 &ro, V3 &rd) {
     const float4 o = ray[2 * (size_t)i], d = ray[2 * (size_t)i + 1];
@@ -153,8 +161,10 @@ __device__ __forceinline__ bool enters_box(const SceneDev &S, V3 ro, V3 rd, floa
 __global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
     __shared__ uint32_t s_wave[BLOCK / WAVE + 1];
     const SceneDev &S = A.S;
+    const uint32_t n_rays = level_rays(A.n_src, A.n_rays);
+    if (blockIdx.x * BLOCK >= n_rays) return;   // the grid covers the capacity of the level
     const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x;
-    bool active = tid < A.n_rays;
+    bool active = tid < n_rays;
     V3 ro, rd;
     if (A.level == 0) {
         int px = 0, py = 0;
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
         float fx = ((float)px + 0.5f) / (float)A.g.W, fy = ((float)py + 0.5f) / (float)A.g.H;
         V3 dir = mix3(mix3(ld3(S.r00), ld3(S.r01), fy), mix3(ld3(S.r10), ld3(S.r11), fy), fx);
         rd = normalize(dir);
-        if (tid < A.n_rays) store_ray(A.cur.ray, tid, ro, rd);
+        if (tid < n_rays) store_ray(A.cur.ray, tid, ro, rd);
     } else {
         uint32_t i = active ? tid : 0;
         load_ray(A.cur.ray, i, ro, rd);
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
             }
         }
     }
-    if (tid < A.n_rays) {
+    if (tid < n_rays) {
         A.cur.ht[tid] = tMin;
         A.cur.hp[tid] = active ? (best | (last << 16)) : 0xfffeffffu;   // 0xfffe in the high half: lane outside the image
         A.cur.hf[tid] = face;
@@ -244,7 +254,7 @@ struct WalkArgs {
 #define LEAF_EMIT_COND
 #endif
 #ifndef RT_REFILL_MIN_IDLE
-#define RT_REFILL_MIN_IDLE 16
+#define RT_REFILL_MIN_IDLE 24
 #endif
 #ifndef RT_SHORT_STACK
 #define RT_SHORT_STACK 8
@@ -586,8 +596,10 @@ __device__ __forceinline__ V3 shadow_dir(const SceneDev &S, int l, V3 point) {
 __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
     __shared__ uint32_t s_wave[BLOCK / WAVE + 1];
     const SceneDev &S = A.S;
+    const uint32_t n_rays = level_rays(A.n_src, A.n_rays);
+    if (blockIdx.x * BLOCK >= n_rays) return;
     const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x;
-    const bool in_range = tid < A.n_rays;
+    const bool in_range = tid < n_rays;
     const uint32_t i = in_range ? tid : 0;
     const uint32_t hp = A.cur.hp[i];
     const bool active = in_range && (hp >> 16) != 0xfffeu;
@@ -726,8 +738,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
 // ---- illuminate (js/8-kd_tree.js:716-820): the local colour of every hit, with the finished shadow bits ----
 __global__ __launch_bounds__(BLOCK) void k_shade_b(LevelArgs A) {
     const SceneDev &S = A.S;
+    const uint32_t n_rays = level_rays(A.n_src, A.n_rays);
+    if (blockIdx.x * BLOCK >= n_rays) return;
     const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x;
-    const bool in_range = tid < A.n_rays;
+    const bool in_range = tid < n_rays;
     const uint32_t i = in_range ? tid : 0;
     const uint32_t hp = A.cur.hp[i];
     const bool active = in_range && (hp >> 16) != 0xfffeu;
@@ -791,9 +805,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade_b(LevelArgs A) {
 }
 
 // parent.color += kRefract * refracted.color, then += kReflect * reflected.color (js/8-kd_tree.js:1041-1054)
-__global__ __launch_bounds__(256) void k_composite(LevelBuf cur, LevelBuf nxt, uint32_t n) {
+__global__ __launch_bounds__(256) void k_composite(LevelBuf cur, LevelBuf nxt, const uint32_t *n_src, uint32_t bound) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= level_rays(n_src, bound)) return;
     float r = cur.cr[i], g = cur.cg[i], b = cur.cb[i];
     int32_t c = cur.refr[i];
     if (c >= 0) {
