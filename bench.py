@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--emulate-shards", type=int, default=0, help="single rank only: trace shard 0 of N (what one GPU of an N-GPU job does, without the exchange)")
     ap.add_argument("--parts", type=int, default=0, help="concurrent slices per GPU (0 = library default)")
+    ap.add_argument("--in-flight", type=int, default=3, help="frames in flight per GPU (contexts that alternate frames); 1 = finish every frame before the next")
+    ap.add_argument("--walk-waves", type=int, default=0, help="persistent walk waves per CU and context (0 = 24, or 12 when the frame is split over more than 4 GPUs)")
+    ap.add_argument("--sync-job", action="store_true", help="the host-synchronised frame job (every stage of the exchange waits on the host)")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (rehearsal on a one-GPU box); default LOCAL_RANK")
     args = ap.parse_args()
@@ -80,14 +83,24 @@ def main():
     cfg = abi.default_config(args.width, args.height, depth=args.depth, shard_index=rank, shard_count=shard_count, device=local,
                              parts=args.parts)
     flat = abi.FlatScene(sc, cfg, scene.camera_rays(args.width, args.height))
-    rt = abi.RayTracerHIP(cfg)
+    pipelined = not args.sync_job and (world == 1 or args.backend == "nccl")
+    n_ctx = max(1, args.in_flight) if pipelined else 1
     t0 = time.perf_counter()
-    rt.setScene(flat)
-    setup_s = time.perf_counter() - t0
-    frame = multi_gpu.FrameJob(rt, comm)
+    rts = []
+    for _ in range(n_ctx):
+        r = abi.RayTracerHIP(cfg)
+        r.setScene(flat)
+        waves = args.walk_waves or (24 if (n_ctx == 1 or shard_count <= 4) else 12)
+        r.setOption("walk_waves_per_cu", waves)
+        rts.append(r)
+    rt = rts[0]
+    setup_s = (time.perf_counter() - t0) / n_ctx
+    frame = multi_gpu.PipelinedFrameJob(rts, comm) if pipelined else multi_gpu.FrameJob(rt, comm)
+    flush = frame.flush if pipelined else (lambda: None)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):   # the first frame sizes the buffers
         frame.step()
+    flush()
     comm.barrier()
     torch.cuda.synchronize()
     lvl_ms = np.zeros(8)
@@ -96,33 +109,45 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame.step()
+    flush()
+    comm.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = comm.max_float(dt)
+    # per-kernel times: device events of the library around every launch, taken from frames traced one at a time after
+    # the timed region (with several frames in flight the kernels of different frames share the GPU)
+    n_detail = min(args.steps, 5)
+    rt.setOption("walk_waves_per_cu", args.walk_waves or 24)
+    for _ in range(n_detail):
+        rt.trace()
+        rt.tone()
         st = rt.stats()
         lvl_ms += np.array(list(st.level_kernel_ms))
         stage_ms += np.array([list(r) for r in st.level_stage_ms])
         trace_ms += st.trace_ms
         comp_ms += st.composite_ms
         tone_ms += st.tone_ms
-    comm.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = comm.max_float(dt)
     st = rt.stats()
     rays = comm.sum_int(int(st.rays_total))
     shadow = comm.sum_int(int(st.shadow_rays))
     per_level = [comm.sum_int(int(x)) for x in st.rays_per_level]
     K = args.steps
-    lvl_ms /= K
-    stage_ms /= K
+    lvl_ms /= n_detail
+    stage_ms /= n_detail
+    trace_ms /= n_detail
+    comp_ms /= n_detail
+    tone_ms /= n_detail
 
     # the same frame with the canvas copied to a host buffer (what a caller without device memory pays);
     # reported beside the metric, never as the metric
     pcie_ms = None
     if world == 1:
         n_pcie = min(K, 5)
+        sync_frame = multi_gpu.FrameJob(rt, comm)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(n_pcie):
-            frame.step()
+            sync_frame.step()
             rt.readRGBA8()
         pcie_ms = (time.perf_counter() - t1) / n_pcie * 1e3
 
@@ -150,7 +175,9 @@ def main():
         "mshadow_rays_per_s": shadow / (dt / K) / 1e6,
         "pcie_inclusive": None if pcie_ms is None else {"ms_per_step": pcie_ms, "value": rays / (pcie_ms * 1e-3) / 1e6,
                                                         "note": "step + rt_read_rgba8 of the 3840x2160 RGBA8 target into pageable host memory"},
-        "trace_only_ms": trace_ms / K, "composite_ms": comp_ms / K, "tone_ms": tone_ms / K,
+        "trace_only_ms": trace_ms, "composite_ms": comp_ms, "tone_ms": tone_ms,
+        "frames_in_flight": n_ctx, "frame_job": "pipelined (stream-ordered, device-resident exchange)" if pipelined else "host-synchronised",
+        "frames_retraced": getattr(frame, "redone", 0),
         "step_kernel_ms": [round(float(x), 4) for x in lvl_ms[:args.depth + 1]],
         "stage_names": ["k_gen_prims", "k_kd_walk", "k_tri_test", "k_shade_b", "k_shade_a"],
         "pipeline_step": "step k = k_gen_prims(level k), k_kd_walk + k_tri_test (closest-hit rays of level k with the shadow rays of level k-1), k_shade_b(level k-1), k_shade_a(level k)",

@@ -188,8 +188,18 @@ int rt_tone_finish(rt_ctx *ctx, double sum_log, uint64_t count, double *Lbar, do
 /* single-GPU convenience: rt_tone_partial + rt_tone_finish */
 int rt_tone(rt_ctx *ctx, double *Lbar, double *sf);
 /* present pass (js/8-kd_tree.js:85-143): SxS box filter, tone operator, canvas RGBA8.
- * canvas_rgba may be NULL: the canvas then stays in device memory (rt_device_canvas) */
+ * canvas_rgba may be NULL: the pass is then only queued on the context's stream and the canvas stays in device
+ * memory (rt_device_canvas) */
 int rt_present(rt_ctx *ctx, uint8_t *canvas_rgba);
+/* The same reduction with nothing returning to the host, for multi-GPU callers that all-reduce on the device:
+ * rt_tone_partial_device queues the reduction and hands out the device address of two doubles,
+ * {sum of log(EPSILON + L), pixel count}; the caller sums them over the ranks in place (on the context's stream, see
+ * rt_stream) and passes the address to rt_tone_finish_device, which queues the Lbar / sf computation; rt_present then
+ * uses them. rt_tone_get waits and returns the Lbar / sf last computed by either path. Device exp/pow may differ from
+ * the host's in the last bit of the double; the present pass receives them rounded to float, as in the reference. */
+int rt_tone_partial_device(rt_ctx *ctx, void **d_sum_count);
+int rt_tone_finish_device(rt_ctx *ctx, const void *d_sum_count);
+int rt_tone_get(rt_ctx *ctx, double *Lbar, double *sf);
 
 /* ---- device-resident access for multi-GPU gathers (no host round trip) ------------------- */
 /* device pointer of the RGBA8 render target (width*S*height*S*4 bytes) */
@@ -204,8 +214,15 @@ int rt_device_shard_rgba8(rt_ctx *ctx, void **dptr, size_t *bytes);
 /* root side of the framebuffer gather: `gathered` (device memory of this context's device) holds
  * n_shards compact shard buffers back to back, each padded to stride_bytes (a multiple of 256);
  * scatters them into this context's full-frame RGBA8 target so that rt_read_rgba8 / rt_present see
- * the whole image. Replaces nothing in the reference (single GPU there). */
+ * the whole image. The scatter is queued on the context's stream (the rt_read_* calls and rt_present follow it in
+ * stream order). Replaces nothing in the reference (single GPU there). */
 int rt_assemble_shards(rt_ctx *ctx, const void *gathered, size_t stride_bytes, int32_t n_shards);
+/* The HIP stream (hipStream_t) on which this context queues its work. Work a caller queues on it - a collective, a
+ * copy - is ordered with the library's kernels without any host synchronisation. No counterpart in the reference. */
+int rt_stream(rt_ctx *ctx, void **stream);
+/* Tuning knobs by name. "walk_waves_per_cu" (1..32, default 24): persistent waves per compute unit of the k-d walk;
+ * two contexts that trace concurrently on one GPU fit side by side at 12. No counterpart in the reference. */
+int rt_set_option(rt_ctx *ctx, const char *name, double value);
 
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 

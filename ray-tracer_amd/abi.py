@@ -147,6 +147,11 @@ def lib():
         L.rt_device_shard_rgba8.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.rt_assemble_shards.argtypes = [vp, vp, C.c_size_t, i32]
         L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.rt_tone_partial_device.argtypes = [vp, C.POINTER(vp)]
+        L.rt_tone_finish_device.argtypes = [vp, vp]
+        L.rt_tone_get.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.rt_stream.argtypes = [vp, C.POINTER(vp)]
+        L.rt_set_option.argtypes = [vp, C.c_char_p, C.c_double]
         _lib = L
     return _lib
 
@@ -271,6 +276,31 @@ class RayTracerHIP:
         Lbar, sf = C.c_double(), C.c_double()
         self._ck(self.L.rt_tone(self.ctx, C.byref(Lbar), C.byref(sf)), "rt_tone")
         return Lbar.value, sf.value
+
+    def tonePartialDevice(self):
+        """Queues the reduction; returns the device address of {sum of log luminance, pixel count} (two doubles)."""
+        p = C.c_void_p()
+        self._ck(self.L.rt_tone_partial_device(self.ctx, C.byref(p)), "rt_tone_partial_device")
+        return p.value
+
+    def toneFinishDevice(self, dptr):
+        self._ck(self.L.rt_tone_finish_device(self.ctx, C.c_void_p(dptr)), "rt_tone_finish_device")
+
+    def toneGet(self):
+        Lbar, sf = C.c_double(), C.c_double()
+        self._ck(self.L.rt_tone_get(self.ctx, C.byref(Lbar), C.byref(sf)), "rt_tone_get")
+        return Lbar.value, sf.value
+
+    def presentQueued(self):
+        self._ck(self.L.rt_present(self.ctx, None), "rt_present")
+
+    def stream(self):
+        p = C.c_void_p()
+        self._ck(self.L.rt_stream(self.ctx, C.byref(p)), "rt_stream")
+        return p.value
+
+    def setOption(self, name, value):
+        self._ck(self.L.rt_set_option(self.ctx, name.encode(), float(value)), "rt_set_option")
 
     def present(self):
         out = np.zeros((self.cfg.height, self.cfg.width, 4), np.uint8)

@@ -105,6 +105,10 @@ struct rt_ctx {
     uint32_t *d_rgba = nullptr, *d_compact = nullptr, *d_canvas = nullptr;
     int32_t *d_hit = nullptr;
     double *d_part_sum = nullptr, *d_tone_out = nullptr;
+    double *d_tone_pair = nullptr;               // {sum of log luminance, pixel count} of this shard, for a device-side all-reduce
+    float *d_tone = nullptr;                     // Lbar, sf as the present pass reads them
+    double *d_tone_d = nullptr;                  // the same in double precision
+    bool tone_on_device = false;                 // Lbar / sf were computed by rt_tone_finish_device: the host copy is stale
     unsigned long long *d_part_cnt = nullptr, *d_tone_cnt = nullptr;
     double Lbar = 0.0, sf = 0.0;
     bool traced = false;
@@ -417,6 +421,9 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     ALLOC(ctx->d_part_cnt, TONE_BLOCKS * sizeof(unsigned long long));
     ALLOC(ctx->d_tone_out, sizeof(double));
     ALLOC(ctx->d_tone_cnt, sizeof(unsigned long long));
+    ALLOC(ctx->d_tone_pair, 2 * sizeof(double));
+    ALLOC(ctx->d_tone, 2 * sizeof(float));
+    ALLOC(ctx->d_tone_d, 2 * sizeof(double));
 #undef ALLOC
     *out = ctx;
     return 0;
@@ -429,7 +436,8 @@ void rt_destroy(rt_ctx *ctx) {
     (void)hipDeviceSynchronize();
     void *ptrs[] = {ctx->d_scene, ctx->d_prims, ctx->d_mats, ctx->d_lights, ctx->d_tris, ctx->d_nodes, ctx->d_ltris,
                     ctx->d_path_first, ctx->d_path_slot, ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_canvas,
-                    ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt};
+                    ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt,
+                    ctx->d_tone_pair, ctx->d_tone, ctx->d_tone_d};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &ev : ctx->ev_misc)
@@ -855,31 +863,47 @@ int rt_read_hit_ids(rt_ctx *ctx, int32_t *ids) {
     return 0;
 }
 
+static int queue_tone_reduction(rt_ctx *ctx) {
+    hipStream_t s = ctx->stream;
+    HIPCK(hipEventRecord(ctx->ev_misc[0], s));
+    int blocks = (int)std::min<uint32_t>((ctx->n0 + 255) / 256, TONE_BLOCKS);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_tone_partial, dim3(blocks), dim3(256), 0, s, ctx->d_compact, ctx->n0, (double)ctx->cfg.L_max,
+                       ctx->d_part_sum, ctx->d_part_cnt);
+    hipLaunchKernelGGL(k_tone_final, dim3(1), dim3(64), 0, s, ctx->d_part_sum, ctx->d_part_cnt, blocks, ctx->d_tone_out,
+                       ctx->d_tone_cnt, ctx->d_tone_pair);
+    HIPCK(hipGetLastError());
+    HIPCK(hipEventRecord(ctx->ev_misc[1], s));
+    return 0;
+}
+
 int rt_tone_partial(rt_ctx *ctx, double *sum_log, uint64_t *count) {
     if (!ctx) return -1;
     if (ctx->host_only) return fail(ctx, "rt_tone_partial: host-only context (created with device = -1)");
     if (!sum_log || !count) return fail(ctx, "rt_tone_partial: null argument");
     if (!ctx->traced) return fail(ctx, "rt_tone_partial: nothing traced yet");
     HIPCK(hipSetDevice(ctx->cfg.device));
+    if (queue_tone_reduction(ctx)) return -1;
     hipStream_t s = ctx->stream;
-    hipEvent_t e0 = ctx->ev_misc[0], e1 = ctx->ev_misc[1];
-    HIPCK(hipEventRecord(e0, s));
-    int blocks = (int)std::min<uint32_t>((ctx->n0 + 255) / 256, TONE_BLOCKS);
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_tone_partial, dim3(blocks), dim3(256), 0, s, ctx->d_compact, ctx->n0, (double)ctx->cfg.L_max,
-                       ctx->d_part_sum, ctx->d_part_cnt);
-    hipLaunchKernelGGL(k_tone_final, dim3(1), dim3(64), 0, s, ctx->d_part_sum, ctx->d_part_cnt, blocks, ctx->d_tone_out,
-                       ctx->d_tone_cnt);
-    HIPCK(hipGetLastError());
-    HIPCK(hipEventRecord(e1, s));
     unsigned long long c = 0;
     HIPCK(hipMemcpyAsync(sum_log, ctx->d_tone_out, sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCK(hipMemcpyAsync(&c, ctx->d_tone_cnt, sizeof c, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     *count = c;
     float ms = 0;
-    HIPCK(hipEventElapsedTime(&ms, e0, e1));
+    HIPCK(hipEventElapsedTime(&ms, ctx->ev_misc[0], ctx->ev_misc[1]));
     ctx->st.tone_ms = ms;
+    return 0;
+}
+
+int rt_tone_partial_device(rt_ctx *ctx, void **d_sum_count) {
+    if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_tone_partial_device: host-only context (created with device = -1)");
+    if (!d_sum_count) return fail(ctx, "rt_tone_partial_device: null argument");
+    if (!ctx->traced) return fail(ctx, "rt_tone_partial_device: nothing traced yet");
+    HIPCK(hipSetDevice(ctx->cfg.device));
+    if (queue_tone_reduction(ctx)) return -1;
+    *d_sum_count = ctx->d_tone_pair;
     return 0;
 }
 
@@ -889,6 +913,40 @@ int rt_tone_finish(rt_ctx *ctx, double sum_log, uint64_t count, double *Lbar, do
     // Lbar = exp(sum / N); sf = ((1.219 + (Ldmax/2)^0.4) / (1.219 + Lbar^0.4))^2.5  (js/8-kd_tree.js:2568-2569)
     ctx->Lbar = exp(sum_log / (double)count);
     ctx->sf = pow((1.219 + pow((double)ctx->cfg.L_dmax * 0.5, 0.4)) / (1.219 + pow(ctx->Lbar, 0.4)), 2.5);
+    ctx->tone_on_device = false;
+    if (Lbar) *Lbar = ctx->Lbar;
+    if (sf) *sf = ctx->sf;
+    if (!ctx->host_only) {
+        HIPCK(hipSetDevice(ctx->cfg.device));
+        hipLaunchKernelGGL(k_set_tone, dim3(1), dim3(1), 0, ctx->stream, ctx->Lbar, ctx->sf, ctx->d_tone, ctx->d_tone_d);
+        HIPCK(hipGetLastError());
+    }
+    return 0;
+}
+
+int rt_tone_finish_device(rt_ctx *ctx, const void *d_sum_count) {
+    if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_tone_finish_device: host-only context (created with device = -1)");
+    if (!d_sum_count) return fail(ctx, "rt_tone_finish_device: null argument");
+    HIPCK(hipSetDevice(ctx->cfg.device));
+    hipLaunchKernelGGL(k_tone_finish, dim3(1), dim3(1), 0, ctx->stream, (const double *)d_sum_count, (double)ctx->cfg.L_dmax,
+                       ctx->d_tone, ctx->d_tone_d);
+    HIPCK(hipGetLastError());
+    ctx->tone_on_device = true;
+    return 0;
+}
+
+int rt_tone_get(rt_ctx *ctx, double *Lbar, double *sf) {
+    if (!ctx) return -1;
+    if (ctx->tone_on_device) {
+        double v[2];
+        HIPCK(hipSetDevice(ctx->cfg.device));
+        HIPCK(hipMemcpyAsync(v, ctx->d_tone_d, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
+        ctx->Lbar = v[0];
+        ctx->sf = v[1];
+        ctx->tone_on_device = false;
+    }
     if (Lbar) *Lbar = ctx->Lbar;
     if (sf) *sf = ctx->sf;
     return 0;
@@ -910,11 +968,32 @@ int rt_present(rt_ctx *ctx, uint8_t *canvas) {
     dim3 grid((c.width + 15) / 16, (c.height + 15) / 16);
     // Lbar and sf reach the shader as float uniforms (js/8-kd_tree.js:2579-2581)
     hipLaunchKernelGGL(k_present, grid, dim3(256), 0, ctx->stream, ctx->d_rgba, c.width, c.height, c.supersampling, c.tr_method,
-                       c.L_max, c.L_dmax, c.A, (float)ctx->Lbar, (float)ctx->sf, ctx->d_canvas);
+                       c.L_max, c.L_dmax, c.A, ctx->d_tone, ctx->d_canvas);
     HIPCK(hipGetLastError());
-    if (canvas) HIPCK(hipMemcpyAsync(canvas, ctx->d_canvas, (size_t)c.width * c.height * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCK(hipStreamSynchronize(ctx->stream));
+    if (canvas) {
+        HIPCK(hipMemcpyAsync(canvas, ctx->d_canvas, (size_t)c.width * c.height * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
+    }
     return 0;
+}
+
+int rt_stream(rt_ctx *ctx, void **stream) {
+    if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_stream: host-only context (created with device = -1)");
+    if (!stream) return fail(ctx, "rt_stream: null argument");
+    *stream = (void *)ctx->stream;
+    return 0;
+}
+
+int rt_set_option(rt_ctx *ctx, const char *name, double value) {
+    if (!ctx) return -1;
+    if (!name) return fail(ctx, "rt_set_option: null name");
+    if (!strcmp(name, "walk_waves_per_cu")) {
+        if (!(value >= 1 && value <= 32)) return fail(ctx, "rt_set_option: walk_waves_per_cu must be in 1..32");
+        ctx->walk_waves_per_cu = (int)value;
+        return 0;
+    }
+    return fail(ctx, "rt_set_option: unknown option");
 }
 
 int rt_device_rgba8(rt_ctx *ctx, void **dptr, size_t *bytes) {
@@ -955,7 +1034,6 @@ int rt_assemble_shards(rt_ctx *ctx, const void *gathered, size_t stride_bytes, i
     hipLaunchKernelGGL(k_assemble, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)gathered,
                        stride, n_shards, ctx->g, ctx->d_rgba);
     HIPCK(hipGetLastError());
-    HIPCK(hipStreamSynchronize(ctx->stream));
     ctx->traced = true;
     return 0;
 }

@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256) void k_tone_partial(const uint32_t *compact, u
 }
 
 __global__ __launch_bounds__(64) void k_tone_final(const double *part_sum, const unsigned long long *part_cnt, int n_parts,
-                                                   double *out_sum, unsigned long long *out_cnt) {
+                                                   double *out_sum, unsigned long long *out_cnt, double *pair) {
     double acc = 0.0;
     unsigned long long cnt = 0;
     for (int i = threadIdx.x; i < n_parts; i += 64) { acc += part_sum[i]; cnt += part_cnt[i]; }
@@ -884,16 +884,34 @@ __global__ __launch_bounds__(64) void k_tone_final(const double *part_sum, const
         acc += __shfl_down(acc, o);
         cnt += __shfl_down(cnt, o);
     }
-    if (threadIdx.x == 0) { *out_sum = acc; *out_cnt = cnt; }
+    if (threadIdx.x == 0) {
+        *out_sum = acc; *out_cnt = cnt;
+        pair[0] = acc; pair[1] = (double)cnt;   // the form an all-reduce (sum) over ranks takes: exact up to 2^53 pixels
+    }
+}
+
+// Lbar = exp(sum / N); sf = ((1.219 + (Ldmax/2)^0.4) / (1.219 + Lbar^0.4))^2.5  (js/8-kd_tree.js:2568-2569), from sums that
+// stayed in device memory. tone[0..1] = Lbar, sf as the float uniforms the present shader receives (js/8-kd_tree.js:2579-2581),
+// tone_d the same in double precision.
+__global__ void k_tone_finish(const double *pair, double L_dmax, float *tone, double *tone_d) {
+    const double Lbar = exp(pair[0] / pair[1]);
+    const double sf = pow((1.219 + pow(L_dmax * 0.5, 0.4)) / (1.219 + pow(Lbar, 0.4)), 2.5);
+    tone[0] = (float)Lbar; tone[1] = (float)sf;
+    tone_d[0] = Lbar; tone_d[1] = sf;
+}
+__global__ void k_set_tone(double Lbar, double sf, float *tone, double *tone_d) {
+    tone[0] = (float)Lbar; tone[1] = (float)sf;
+    tone_d[0] = Lbar; tone_d[1] = sf;
 }
 
 // Present pass, js/8-kd_tree.js:85-143: S x S NEAREST taps (offsets divide by 800*S / 600*S, the WIDTH and
 // HEIGHT the reference script holds when it builds the shader string, js/8-kd_tree.js:55,110-111), scale by
 // L_MAX, Ward (x sf) or Reinhard, divide by L_DMAX, quantise.
 __global__ __launch_bounds__(256) void k_present(const uint32_t *rgba, int W, int H, int S, int method, float L_max,
-                                                 float L_dmax, float Akey, float Lbar, float sf, uint32_t *canvas) {
+                                                 float L_dmax, float Akey, const float *tone, uint32_t *canvas) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= W || y >= H) return;
+    const float Lbar = tone[0], sf = tone[1];
     const int TW = W * S, TH = H * S;
     const float offW = (float)(800 * S), offH = (float)(600 * S);
     float tx = ((float)x + 0.5f) / (float)W, ty = ((float)y + 0.5f) / (float)H;

@@ -14,20 +14,23 @@ import numpy as np
 
 
 class Comm:
-    def __init__(self, rank, world, local_rank=0, backend="nccl", device=None):
+    def __init__(self, rank, world, local_rank=0, backend="nccl", device=None, single_rank_group=False):
         """backend "nccl": collectives run on GPU tensors over RCCL. backend "gloo" with a cuda `device` is the
         rehearsal mode (several ranks sharing one GPU, which RCCL refuses): tensors are staged through the host."""
         self.rank, self.world, self.local = rank, world, local_rank
         self.dist = None
+        self.side = None
         self.device = device or "cpu"
         self.backend = backend
         if backend == "nccl":
             self.device = device or "cuda:%d" % local_rank
-        if world > 1:
+        if world > 1 or single_rank_group:   # a one-rank group runs every collective call (tests)
             import torch.distributed as dist
             if not dist.is_initialized():
                 dist.init_process_group(backend=backend, rank=rank, world_size=world)
             self.dist = dist
+            # host-side flags travel over their own gloo group, so that they never queue behind device collectives
+            self.side = dist.new_group(backend="gloo") if backend == "nccl" else None
 
     def barrier(self):
         if self.dist:
@@ -53,6 +56,18 @@ class Comm:
         import torch.distributed as dist
         import torch
         return int(self._reduce(int(v), torch.int64, dist.ReduceOp.SUM)) if self.dist else v
+
+    def any_flag(self, flag):
+        """True on every rank when `flag` is true on any rank (host-side, no device work)."""
+        if not self.dist:
+            return bool(flag)
+        import torch
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if self.side is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.side)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return bool(t.item())
 
     def allreduce_tone(self, sum_log, count):
         """(sum of log luminance, pixel count) summed over ranks; float64, so the count is exact to 2^53."""
@@ -154,3 +169,84 @@ class FrameJob:
         if comm.rank == 0:
             sh.present()
         return self.Lbar, self.sf
+
+
+class PipelinedFrameJob:
+    """The same frame as FrameJob, queued without host synchronisation and with several frames in flight.
+
+    Every context (one per frame in flight) owns a HIP stream; the trace, the luminance reduction, the RCCL all-reduce
+    of the two sums (in place, in the library's device memory), the tile gather, the assemble, the tone finish and the
+    present pass of a frame are all queued on that stream, so the device orders them and the host only waits - one
+    step later - for the trace's buffer check (rt_trace_end). While the exchange of frame i runs, the kernels of frame
+    i+1 (another context, another stream) fill the GPU. Needs device-side collectives: backend "nccl", or one rank."""
+
+    def __init__(self, rts, comm):
+        import torch
+        assert comm.dist is None or comm.backend == "nccl", "the pipelined job needs RCCL (or a single rank)"
+        self.torch, self.comm = torch, comm
+        self.slots = []
+        for rt in rts:
+            sh = HipShard(rt, comm.device)
+            st = torch.cuda.ExternalStream(rt.stream(), device=comm.device)
+            gathered = (torch.empty(comm.world * sh.stride, dtype=torch.uint8, device=comm.device)
+                        if comm.rank == 0 and comm.dist is not None else None)
+            self.slots.append({"rt": rt, "shard": sh, "stream": st, "gathered": gathered, "busy": False, "pair": None})
+        self.i = 0
+        self.redone = 0
+
+    def _post(self, slot):
+        """Everything behind the trace of one frame, queued on the slot's stream."""
+        rt, sh, comm, torch = slot["rt"], slot["shard"], self.comm, self.torch
+        dptr = rt.tonePartialDevice()
+        if slot["pair"] is None:
+            slot["pair"] = torch.as_tensor(_DevView64(dptr, 2), device=comm.device)
+        if comm.dist is not None:
+            comm.dist.all_reduce(slot["pair"])
+            buf, stride = sh.shard_bytes()
+            parts = list(slot["gathered"].split(stride)) if comm.rank == 0 else None
+            comm.dist.gather(buf, gather_list=parts, dst=0)
+            if comm.rank == 0:
+                rt._ck(rt.L.rt_assemble_shards(rt.ctx, C.c_void_p(slot["gathered"].data_ptr()), C.c_size_t(stride), comm.world),
+                       "rt_assemble_shards")
+        rt.toneFinishDevice(dptr)
+        if comm.rank == 0:
+            rt.presentQueued()
+
+    def _finish(self, slot):
+        if not slot["busy"]:
+            return
+        slot["busy"] = False
+        # every rank must take the same decision: a rank whose buffers overflowed traced again, and the sums and
+        # tiles it sent were wrong, so all ranks repeat the exchange of that frame
+        redo = self.comm.any_flag(slot["rt"].traceEnd())
+        if redo:
+            self.redone += 1
+            with self.torch.cuda.stream(slot["stream"]):
+                self._post(slot)
+
+    def step(self):
+        """Queues one frame on the next context, then completes the frame queued before it on the other one."""
+        slot = self.slots[self.i % len(self.slots)]
+        self._finish(slot)              # the context is reused: its previous frame must be checked first
+        with self.torch.cuda.stream(slot["stream"]):
+            slot["rt"].traceBegin()
+            self._post(slot)
+        slot["busy"] = True
+        self.i += 1
+        if len(self.slots) == 1:
+            self._finish(slot)
+
+    def flush(self):
+        for k in range(len(self.slots)):
+            self._finish(self.slots[(self.i + k) % len(self.slots)])
+
+    def tone(self, k=-1):
+        """Lbar, sf of the frame last completed on context k (waits for its stream)."""
+        return self.slots[k]["rt"].toneGet()
+
+
+class _DevView64:
+    """Zero-copy torch view of `n` doubles of device memory owned by the HIP library."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}

@@ -206,3 +206,89 @@ def test_parts_do_not_change_the_image():
                      st.rays_total, st.shadow_rays, list(st.rays_per_level)))
         rt.close()
     assert outs[0] == outs[1]
+
+
+def test_pipelined_frames_equal_synchronous_ones():
+    """Two contexts alternate frames with everything queued on their streams (rt_trace_begin, device-resident tone,
+    queued present, rt_trace_end one frame later): every frame must equal the one-call-at-a-time result. The light
+    moves between frames, so a context that mixed up frames would show."""
+    import ctypes as C
+    import torch
+    from ray_tracer_amd import multi_gpu, scene
+    flat = make_flat("bun_zipper_res4.ply", 331, 203, depth=4, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    rts = []
+    for _ in range(2):
+        rt = abi.RayTracerHIP(flat.cfg)
+        rt.setScene(flat)
+        rt.setOption("walk_waves_per_cu", 12)
+        rts.append(rt)
+    comm = multi_gpu.Comm(0, 1, 0, backend=None, device="cuda:0")
+    job = multi_gpu.PipelinedFrameJob(rts, comm)
+    ref = abi.RayTracerHIP(flat.cfg)
+    ref.setScene(flat)
+
+    def lights_at(t):
+        x = 500.0 * np.cos(2.0 * np.pi * (t % 60.0) / 60.0)
+        return [((x, 300.0, x - 280.0), flat.lights[0][1])] + list(flat.lights[1:])
+
+    times = [0.0, 3.0, 6.0, 9.0, 12.0]
+    for i, t in enumerate(times):
+        rts[i % 2].setLights(lights_at(t), flat.n_lights_loop)
+        job.step()
+    job.flush()
+    torch.cuda.synchronize()
+    for k, t in ((0, times[4]), (1, times[3])):      # the last frame each context traced
+        ref.setLights(lights_at(t), flat.n_lights_loop)
+        ref.trace()
+        wl, ws = ref.tone()
+        want_canvas = ref.present()
+        rt = rts[k]
+        assert np.array_equal(rt.readRGBA8(), ref.readRGBA8())
+        assert np.array_equal(rt.readFloat(), ref.readFloat(), equal_nan=True)
+        gl, gs = rt.toneGet()
+        assert abs(gl - wl) <= 1e-12 * wl and abs(gs - ws) <= 1e-12 * ws
+        assert np.float32(gs) == np.float32(ws)
+        p, n = C.c_void_p(), C.c_size_t()
+        assert rt.L.rt_device_canvas(rt.ctx, C.byref(p), C.byref(n)) == 0
+        canvas = torch.as_tensor(multi_gpu._DevView(p.value, n.value), device="cuda:0").cpu().numpy()
+        assert np.array_equal(canvas.reshape(want_canvas.shape), want_canvas)
+        assert rt.stats().rays_total == ref.stats().rays_total
+
+
+def test_pipelined_job_with_device_collectives_one_rank():
+    """The N > 1 branch of the pipelined job on a one-rank RCCL group: the all-reduce runs in place on the library's
+    device memory, the gather fills the root's buffer, rt_assemble_shards scatters it back - all queued on the
+    context's stream. With one rank the exchange must leave the frame unchanged."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from ray_tracer_amd import multi_gpu
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    flat = make_flat("bun_zipper_res4.ply", 203, 117, depth=3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    rts = []
+    for _ in range(2):
+        rt = abi.RayTracerHIP(flat.cfg)
+        rt.setScene(flat)
+        rts.append(rt)
+    comm = multi_gpu.Comm(0, 1, 0, backend="nccl", device="cuda:0", single_rank_group=True)
+    try:
+        job = multi_gpu.PipelinedFrameJob(rts, comm)
+        for _ in range(4):
+            job.step()
+        job.flush()
+        torch.cuda.synchronize()
+        ref = abi.RayTracerHIP(flat.cfg)
+        ref.setScene(flat)
+        ref.trace()
+        wl, ws = ref.tone()
+        for rt in rts:
+            assert np.array_equal(rt.readRGBA8(), ref.readRGBA8())
+            gl, gs = rt.toneGet()
+            assert abs(gl - wl) <= 1e-12 * wl and np.float32(gs) == np.float32(ws)
+    finally:
+        comm.close()
