@@ -1,6 +1,7 @@
 // See kd_build.h. Reference: KdTree.buildTree / faceBoxOverlap / axisTest_* / planeBoxOverlap,
 // js/8-kd_tree.js:1647-1970.
 #include "kd_build.h"
+#include "kd_sat.h"
 
 #include <algorithm>
 #include <atomic>
@@ -16,74 +17,10 @@ struct BoxD { double lo[3], hi[3]; };
 struct BoxF { float lo[3], hi[3]; };
 struct MeshRef { const double *v; const uint32_t *f; };
 
-// One separating-axis test of the reference's axisTest_* family (js/8-kd_tree.js:1829-1929):
-// projections pa/pb of two vertices against the box radius on that axis.
-static inline bool separated(double pa, double pb, double rad) {
-    return pa < pb ? (pa > rad || pb < -rad) : (pb > rad || pa < -rad);
-}
-
-// Triangle/box overlap exactly as js/8-kd_tree.js:1737-1827 evaluates it. P = vertices relative to the
-// box centre, H = half extents. The reference forms the normal with Vector3.cross(), which in r84
-// overwrites its receiver: after js/8-kd_tree.js:1760 the "first edge" is the normal, and the first three
-// axis tests (js/8-kd_tree.js:1762-1773) use the normal's components. Kept as is - it decides which faces
-// each child receives.
+// Triangle/box overlap: kd_sat.h (shared with the device builder)
 static bool tri_box_overlap(const MeshRef &m, const BoxD &b, uint32_t face) {
-    double H[3], Cn[3], P[3][3];
-    for (int k = 0; k < 3; k++) {
-        Cn[k] = (b.lo[k] + b.hi[k]) * 0.5;
-        H[k] = std::fabs(b.hi[k] - b.lo[k]) * 0.5;
-    }
-    for (int i = 0; i < 3; i++) {
-        const double *s = m.v + 3 * (size_t)m.f[3 * (size_t)face + i];
-        for (int k = 0; k < 3; k++) P[i][k] = s[k] - Cn[k];
-    }
-    double E1[3], E2[3], N[3];
-    {
-        double E0[3];
-        for (int k = 0; k < 3; k++) {
-            E0[k] = P[1][k] - P[0][k];
-            E1[k] = P[2][k] - P[1][k];
-            E2[k] = P[0][k] - P[2][k];
-        }
-        N[0] = E0[1] * E1[2] - E0[2] * E1[1];
-        N[1] = E0[2] * E1[0] - E0[0] * E1[2];
-        N[2] = E0[0] * E1[1] - E0[1] * E1[0];
-    }
-    // projection helpers: X-type uses (y,z), Y-type (x,z) with the reference's signs, Z-type (x,y)
-    auto px = [&](const double *e, int i) { return e[2] * P[i][1] - e[1] * P[i][2]; };
-    auto py = [&](const double *e, int i) { return -e[2] * P[i][0] + e[0] * P[i][2]; };
-    auto pz = [&](const double *e, int i) { return e[1] * P[i][0] - e[0] * P[i][1]; };
-    auto rx = [&](const double *e) { return std::fabs(e[2]) * H[1] + std::fabs(e[1]) * H[2]; };
-    auto ry = [&](const double *e) { return std::fabs(e[2]) * H[0] + std::fabs(e[0]) * H[2]; };
-    auto rz = [&](const double *e) { return std::fabs(e[1]) * H[0] + std::fabs(e[0]) * H[1]; };
-
-    // "edge 0" = the normal: X01, Y02, Z12
-    if (separated(px(N, 0), px(N, 2), rx(N))) return false;
-    if (separated(py(N, 0), py(N, 2), ry(N))) return false;
-    if (separated(pz(N, 1), pz(N, 2), rz(N))) return false;
-    // edge 1: X01, Y02, Z0
-    if (separated(px(E1, 0), px(E1, 2), rx(E1))) return false;
-    if (separated(py(E1, 0), py(E1, 2), ry(E1))) return false;
-    if (separated(pz(E1, 0), pz(E1, 1), rz(E1))) return false;
-    // edge 2: X2, Y1, Z12
-    if (separated(px(E2, 0), px(E2, 1), rx(E2))) return false;
-    if (separated(py(E2, 0), py(E2, 1), ry(E2))) return false;
-    if (separated(pz(E2, 1), pz(E2, 2), rz(E2))) return false;
-
-    for (int k = 0; k < 3; k++) {
-        double mn = std::fmin(P[0][k], std::fmin(P[1][k], P[2][k]));
-        double mx = std::fmax(P[0][k], std::fmax(P[1][k], P[2][k]));
-        if (mn > H[k] || mx < -H[k]) return false;
-    }
-    // planeBoxOverlap(normal, vert0, halfsize), js/8-kd_tree.js:1931-1970
-    double vmin[3], vmax[3];
-    for (int k = 0; k < 3; k++) {
-        double v = P[0][k];
-        if (N[k] > 0) { vmin[k] = -H[k] - v; vmax[k] = H[k] - v; }
-        else { vmin[k] = H[k] - v; vmax[k] = -H[k] - v; }
-    }
-    if (N[0] * vmin[0] + N[1] * vmin[1] + N[2] * vmin[2] > 0) return false;
-    return N[0] * vmax[0] + N[1] * vmax[1] + N[2] * vmax[2] >= 0;
+    const uint32_t *f = m.f + 3 * (size_t)face;
+    return kd_tri_box_overlap(m.v + 3 * (size_t)f[0], m.v + 3 * (size_t)f[1], m.v + 3 * (size_t)f[2], b.lo, b.hi);
 }
 
 constexpr uint32_t T_INTERNAL = 1u << 30, T_EMPTY = 2u << 30, T_LEAF = 3u << 30;
