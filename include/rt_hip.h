@@ -151,6 +151,10 @@ int rt_set_mesh(rt_ctx *ctx, const double *verts, int32_t n_verts, const uint32_
                 const uint32_t *face_mat, int32_t n_faces);
 /* builds the median-split tree over all faces and uploads the compact device layout */
 int rt_build_kdtree(rt_ctx *ctx);
+/* The same tree, bit for bit, built level by level on the GPU and left in device memory: for geometry that changes
+ * every frame (the reference rebuilds while objects are dragged, js/8-kd_tree.js:2494-2522). Only vertices, faces and
+ * material slots cross PCIe. rt_kdtree_counts / rt_export_kdtree_reference work on it like on the host-built tree. */
+int rt_build_kdtree_device(rt_ctx *ctx);
 /* sizes of the canonical (reference-layout) export */
 int rt_kdtree_counts(rt_ctx *ctx, int64_t *n_nodes, int64_t *n_leaves);
 /* canonical export for the bit-exact check: `nodes` receives n_nodes (heapIndex, metadata)

@@ -129,6 +129,7 @@ def lib():
         L.rt_set_camera.argtypes = [vp, vp, vp, vp, vp, vp]
         L.rt_set_mesh.argtypes = [vp, vp, i32, vp, vp, i32]
         L.rt_build_kdtree.argtypes = [vp]
+        L.rt_build_kdtree_device.argtypes = [vp]
         L.rt_kdtree_counts.argtypes = [vp, i64p, i64p]
         L.rt_export_kdtree_reference.argtypes = [vp, vp, vp, vp]
         L.rt_trace.argtypes = [vp]
@@ -189,7 +190,7 @@ class RayTracerHIP:
         except Exception:
             pass
 
-    def setScene(self, flat, build_kd=True):
+    def setScene(self, flat, build_kd=True, kd_on_device=False):
         prims, mats, lights = flat.prim_array(), flat.mat_array(), flat.light_array()
         self._ck(self.L.rt_set_primitives(self.ctx, C.addressof(prims) if len(prims) else None, len(prims)), "rt_set_primitives")
         self._ck(self.L.rt_set_materials(self.ctx, C.addressof(mats) if len(mats) else None, len(mats)), "rt_set_materials")
@@ -202,7 +203,7 @@ class RayTracerHIP:
         if flat.cfg.render_triangles and len(flat.faces):
             self.setMesh(flat.verts, flat.faces, flat.face_mat)
             if build_kd and flat.cfg.use_kd_tree:
-                self.buildKdTree()
+                self.buildKdTree(on_device=kd_on_device)
 
     def setCamera(self, pos, r00, r01, r10, r11):
         a = [np.ascontiguousarray(x, np.float32) for x in (pos, r00, r01, r10, r11)]
@@ -220,8 +221,11 @@ class RayTracerHIP:
         m = np.ascontiguousarray(face_mat, np.uint32)
         self._ck(self.L.rt_set_mesh(self.ctx, v.ctypes.data, len(v), f.ctypes.data, m.ctypes.data, len(f)), "rt_set_mesh")
 
-    def buildKdTree(self):
-        self._ck(self.L.rt_build_kdtree(self.ctx), "rt_build_kdtree")
+    def buildKdTree(self, on_device=False):
+        if on_device:
+            self._ck(self.L.rt_build_kdtree_device(self.ctx), "rt_build_kdtree_device")
+        else:
+            self._ck(self.L.rt_build_kdtree(self.ctx), "rt_build_kdtree")
 
     def exportKdTree(self):
         nn, nl = C.c_int64(), C.c_int64()

@@ -1,0 +1,87 @@
+// Device-side k-d tree builder: the same tree as kd_build.h (KdTree.buildTree, js/8-kd_tree.js:1647-1732), bit for bit,
+// built level by level on the GPU and left in device memory in the layout the traversal kernels read. Meant for
+// geometry that changes every frame (the reference rebuilds its tree while objects are dragged,
+// js/8-kd_tree.js:2494-2522): nothing but the vertices, the faces and their materials crosses PCIe.
+// Include from .hip sources only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "kd_build.h"
+#include "rt_device.h"
+
+namespace rt {
+
+// result of a build; every pointer is device memory owned by the builder and valid until its next build
+struct GpuKdTree {
+    KdNodeDev *nodes = nullptr;     // treelet layout (see relayout_treelets in kd_build.cpp), leaves in device form
+    uint32_t n_node_slots = 0;
+    TriDev *tris = nullptr;         // face order
+    TriDev *ltris = nullptr;        // leaf order
+    uint32_t n_slots = 0;
+    uint32_t *path_slot = nullptr;  // 2^PATH_BITS entries
+    uint2 *pairs = nullptr;         // (heap index, reference metadata) of every node, unordered
+    uint32_t n_nodes = 0;
+    int32_t *leaves = nullptr;      // reference leaf table: n_leaves x 4 face indices, -1 = unused
+    uint32_t n_leaves = 0;
+    double root_box[6] = {0, 0, 0, 0, 0, 0};
+    int64_t n_internal = 0, n_leaf = 0, n_empty = 0;
+    int depth = 0;
+    double build_ms = 0;            // device time of the last build
+};
+
+class GpuKdBuilder {
+public:
+    GpuKdBuilder() = default;
+    ~GpuKdBuilder();
+    GpuKdBuilder(const GpuKdBuilder &) = delete;
+    GpuKdBuilder &operator=(const GpuKdBuilder &) = delete;
+
+    // verts: n_verts*3 doubles; faces: n_faces*3 indices; face_mat: n_faces material slots (-1 = none), all in
+    // host memory. Needs n_faces > 4 and max_depth > 1 (smaller inputs have a one-node tree: use the host builder).
+    // Returns 0, or -1 with a message in `err`.
+    int build(hipStream_t stream, const double *verts, int64_t n_verts, const uint32_t *faces, const int32_t *face_mat,
+              int64_t n_faces, int max_depth, double infinity, std::string &err);
+
+    GpuKdTree tree;
+
+private:
+    struct LevelNodes {
+        double *blo = nullptr, *bhi = nullptr;   // builder's box, double precision: [3*i + axis]
+        float *flo = nullptr, *fhi = nullptr;    // the shader's box: float32 halving sequence
+        uint32_t *heap = nullptr, *start = nullptr, *count = nullptr, *pos = nullptr;
+    };
+    int build_once(hipStream_t stream, const double *verts, int64_t n_verts, const uint32_t *faces, const int32_t *face_mat,
+                   int64_t n_faces, int max_depth, double infinity, std::string &err);   // 1 = a list ran out and was enlarged
+    int reserve(int64_t n_verts, int64_t n_faces, std::string &err);
+    int grow_pool = 1, grow_nodes = 1, grow_leaves = 1;
+    int ensure_nodes(hipStream_t s, uint32_t slots, std::string &err);
+    void release();
+
+    // inputs
+    double *d_verts = nullptr;
+    uint32_t *d_faces = nullptr;
+    int32_t *d_face_mat = nullptr;
+    size_t cap_verts = 0, cap_faces = 0;
+    // working set
+    LevelNodes lv[2];
+    uint32_t cap_level_nodes = 0;
+    uint32_t *pool_face[2] = {nullptr, nullptr}, *pool_owner[2] = {nullptr, nullptr};
+    uint32_t cap_pool = 0;
+    uint32_t *flags = nullptr, *scanned = nullptr;          // 2 * cap_pool + 1
+    uint32_t *child_flag = nullptr, *child_scan = nullptr;  // 2 * cap_level_nodes + 1
+    uint32_t *child_count = nullptr, *child_start = nullptr, *owner_map = nullptr;
+    unsigned long long *code_count = nullptr, *code_scan = nullptr;   // 2^PATH_BITS + 1
+    uint32_t *leaf_heap = nullptr, *leaf_count = nullptr, *leaf_pos = nullptr, *leaf_faces = nullptr;
+    uint32_t cap_leaves = 0, cap_pairs = 0;
+    uint32_t *counters = nullptr;                            // device: leaves, pairs, empties, root box keys
+    uint32_t *h_counters = nullptr;                          // pinned
+    void *scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    uint32_t cap_node_slots = 0, cap_slots = 0, cap_tris = 0, cap_leaf_table = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+}  // namespace rt

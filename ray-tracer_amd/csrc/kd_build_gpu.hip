@@ -1,0 +1,531 @@
+// See kd_build_gpu.h. Reference: KdTree.buildTree / faceBoxOverlap, js/8-kd_tree.js:1647-1970.
+//
+// The reference builds depth-first with an explicit stack. The same tree falls out of a level-by-level build, because
+// a node depends on its parent only: its box is the parent's box halved on the axis of its depth
+// (js/8-kd_tree.js:1689-1702), its faces are the parent's faces that pass the triangle/box test, in the parent's order
+// (js/8-kd_tree.js:1705-1711). What the depth-first order decides is the numbering of the leaves (the reference pops
+// the upper child first, js/8-kd_tree.js:1677,:1718); it is restored at the end from the leaves' positions in the tree.
+//
+// One level = all nodes of one depth that still split ("active"). Their face lists sit back to back in a pool.
+//   k_kd_test      one lane per (node, face): the two child boxes, two overlap tests, two flags
+//   scan           exclusive sum over the flags, laid out per node as [flags of child 0][flags of child 1]: a child's
+//                  list is contiguous in the next pool and keeps the parent's order
+//   k_kd_scatter   faces to their places in the next pool
+//   k_kd_classify  one lane per child: size of its list -> splits again / leaf / empty leaf
+//   scan           rank of the children that split = their index among the next level's active nodes
+//   k_kd_emit      node records in the treelet layout, boxes of the next level, leaves to a list
+// and at the end the leaves are numbered and their triangles laid out in leaf order (k_kd_leaf_*).
+#include "kd_build_gpu.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+#include "kd_sat.h"
+
+namespace rt {
+namespace {
+
+constexpr uint32_t T_INTERNAL = 1u << 30, T_EMPTY = 2u << 30, T_LEAF = 3u << 30;
+constexpr uint32_t NONE = 0xffffffffu;
+constexpr uint32_t CODES = 1u << PATH_BITS;
+enum { C_LEAVES = 0, C_PAIRS = 1, C_EMPTY = 2, C_WORDS = 4 };
+
+struct Nodes {
+    double *blo, *bhi;
+    float *flo, *fhi;
+    uint32_t *heap, *start, *count, *pos;
+};
+
+// doubles as unsigned keys that order like the values (no NaN here)
+__device__ __forceinline__ unsigned long long order_key(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+inline double key_value(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double x;
+    memcpy(&x, &b, sizeof x);
+    return x;
+}
+inline unsigned long long host_order_key(double x) {
+    unsigned long long b;
+    memcpy(&b, &x, sizeof b);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// root box: x from vertex 0, y from vertex 1, z from vertex 2 of each face (js/8-kd_tree.js:1657-1669)
+__global__ __launch_bounds__(256) void k_kd_root_box(const double *verts, const uint32_t *faces, uint32_t n_faces,
+                                                     unsigned long long *keys /* lo xyz, hi xyz */) {
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_faces) return;
+    for (int k = 0; k < 3; k++) {
+        const unsigned long long c = order_key(verts[3 * (size_t)faces[3 * (size_t)f + k] + k]);
+        atomicMin(&keys[k], c);
+        atomicMax(&keys[3 + k], c);
+    }
+}
+
+// triangles in face order: float32 narrowing of the vertices (js/8-kd_tree.js:2462-2464), edges formed in float32
+__global__ __launch_bounds__(256) void k_kd_make_tris(const double *verts, const uint32_t *faces, const int32_t *face_mat,
+                                                      uint32_t n_faces, TriDev *tris) {
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_faces) return;
+    float v[3][3];
+    for (int j = 0; j < 3; j++)
+        for (int k = 0; k < 3; k++) v[j][k] = (float)verts[3 * (size_t)faces[3 * (size_t)f + j] + k];
+    TriDev t;
+    for (int k = 0; k < 3; k++) { t.v0[k] = v[0][k]; t.e1[k] = v[1][k] - v[0][k]; t.e2[k] = v[2][k] - v[0][k]; }
+    t.mat = face_mat[f];
+    t.face = (int32_t)f;
+    t.code = 0;
+    tris[f] = t;
+}
+
+__global__ __launch_bounds__(256) void k_kd_iota(uint32_t *a, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) a[i] = i;
+}
+
+__device__ __forceinline__ uint32_t owner_of(const uint32_t *pool_owner, const uint32_t *owner_map, uint32_t p) {
+    const uint32_t raw = pool_owner[p];
+    return owner_map ? owner_map[raw] : raw;
+}
+
+__global__ __launch_bounds__(256) void k_kd_test(const double *verts, const uint32_t *faces, const uint32_t *pool_face,
+                                                 const uint32_t *pool_owner, const uint32_t *owner_map, uint32_t n_pool,
+                                                 Nodes cur, int axis, uint32_t *flags) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pool) return;
+    const uint32_t o = owner_of(pool_owner, owner_map, p);
+    if (o == NONE) return;   // this face belongs to a leaf
+    const uint32_t start = cur.start[o], cnt = cur.count[o], j = p - start;
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; k++) { lo[k] = cur.blo[3 * (size_t)o + k]; hi[k] = cur.bhi[3 * (size_t)o + k]; }
+    const uint32_t *f = faces + 3 * (size_t)pool_face[p];
+    const double *s0 = verts + 3 * (size_t)f[0], *s1 = verts + 3 * (size_t)f[1], *s2 = verts + 3 * (size_t)f[2];
+    // child i spans [min + 0.5*i*ext, min + 0.5*(i+1)*ext] on the split axis (js/8-kd_tree.js:1692-1701)
+    const double base = lo[axis], ext = hi[axis] - lo[axis];
+    for (int i = 0; i < 2; i++) {
+        lo[axis] = base + 0.5 * (double)i * ext;
+        hi[axis] = base + 0.5 * (double)(i + 1) * ext;
+        flags[2 * (size_t)start + (size_t)i * cnt + j] = kd_tri_box_overlap(s0, s1, s2, lo, hi) ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_kd_scatter(const uint32_t *pool_face, const uint32_t *pool_owner, const uint32_t *owner_map,
+                                                    uint32_t n_pool, Nodes cur, const uint32_t *flags, const uint32_t *scanned,
+                                                    uint32_t next_cap, uint32_t *next_face, uint32_t *next_owner) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pool) return;
+    const uint32_t o = owner_of(pool_owner, owner_map, p);
+    if (o == NONE) return;
+    const uint32_t start = cur.start[o], cnt = cur.count[o], j = p - start;
+    for (uint32_t i = 0; i < 2; i++) {
+        const size_t e = 2 * (size_t)start + (size_t)i * cnt + j;
+        if (flags[e]) {
+            const uint32_t dst = scanned[e];
+            if (dst < next_cap) { next_face[dst] = pool_face[p]; next_owner[dst] = 2 * o + i; }
+        }
+    }
+}
+
+// child c of active node o is child 2*o + c of the level
+__global__ __launch_bounds__(256) void k_kd_classify(Nodes cur, uint32_t n_active, const uint32_t *scanned, int child_depth,
+                                                     int max_depth, uint32_t *child_start, uint32_t *child_count, uint32_t *child_flag) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 2 * n_active) return;
+    const uint32_t o = t >> 1, c = t & 1u;
+    const uint32_t start = cur.start[o], cnt = cur.count[o];
+    const size_t e0 = 2 * (size_t)start + (size_t)c * cnt;
+    const uint32_t first = scanned[e0], n = scanned[e0 + cnt] - first;
+    child_start[t] = first;
+    child_count[t] = n;
+    child_flag[t] = (n > 4u && child_depth < max_depth) ? 1u : 0u;   // js/8-kd_tree.js:1683
+}
+
+struct EmitOut {
+    KdNodeDev *nodes;
+    uint32_t node_cap;
+    uint2 *pairs;
+    uint32_t cap_pairs;
+    uint32_t *leaf_heap, *leaf_count, *leaf_pos, *leaf_faces;
+    uint32_t cap_leaves;
+    uint32_t *counters;
+};
+
+__global__ __launch_bounds__(256) void k_kd_emit(Nodes cur, Nodes nxt, uint32_t n_active, uint32_t next_cap_nodes, int axis,
+                                                 int opens_block, uint32_t block_base, const uint32_t *child_start,
+                                                 const uint32_t *child_count, const uint32_t *child_flag, const uint32_t *child_scan,
+                                                 const uint32_t *next_face, uint32_t pool_cap, uint32_t *owner_map, EmitOut out) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 2 * n_active) return;
+    const uint32_t o = t >> 1, c = t & 1u;
+    const uint32_t pos = cur.pos[o], heap = cur.heap[o];
+    // treelet layout (kd_build.cpp: relayout_treelets): a 16-slot block holds a pair, its four children and eight
+    // grandchildren; the pairs below the third level open blocks of their own
+    const uint32_t kids = opens_block ? block_base + 16u * o : (pos & ~15u) + 2u * (pos & 15u) + 2u;
+    const float flo = cur.flo[3 * (size_t)o + axis], fhi = cur.fhi[3 * (size_t)o + axis];
+    const float split = flo + 0.5f * (fhi - flo);   // the shader's plane (js/8-kd_tree.js:873, :885)
+    if (c == 0u) {
+        if (pos < out.node_cap) out.nodes[pos] = KdNodeDev{split, T_INTERNAL | ((uint32_t)axis << 28) | kids};
+        const uint32_t pi = atomicAdd(&out.counters[C_PAIRS], 1u);
+        if (pi < out.cap_pairs) out.pairs[pi] = make_uint2(heap, T_INTERNAL);
+    }
+    const uint32_t cpos = kids + c, cheap = 2u * heap + 1u + c, n = child_count[t];
+    if (child_flag[t]) {
+        const uint32_t idx = child_scan[t];
+        owner_map[t] = idx;
+        if (idx >= next_cap_nodes) return;
+        const double base = cur.blo[3 * (size_t)o + axis], ext = cur.bhi[3 * (size_t)o + axis] - base;
+        for (int k = 0; k < 3; k++) {
+            nxt.blo[3 * (size_t)idx + k] = cur.blo[3 * (size_t)o + k];
+            nxt.bhi[3 * (size_t)idx + k] = cur.bhi[3 * (size_t)o + k];
+            nxt.flo[3 * (size_t)idx + k] = cur.flo[3 * (size_t)o + k];
+            nxt.fhi[3 * (size_t)idx + k] = cur.fhi[3 * (size_t)o + k];
+        }
+        nxt.blo[3 * (size_t)idx + axis] = base + 0.5 * (double)c * ext;
+        nxt.bhi[3 * (size_t)idx + axis] = base + 0.5 * (double)(c + 1u) * ext;
+        if (c == 0u) nxt.fhi[3 * (size_t)idx + axis] = split;
+        else nxt.flo[3 * (size_t)idx + axis] = split;
+        nxt.heap[idx] = cheap;
+        nxt.start[idx] = child_start[t];
+        nxt.count[idx] = n;
+        nxt.pos[idx] = cpos;
+        return;
+    }
+    owner_map[t] = NONE;
+    if (n == 0u) {
+        if (cpos < out.node_cap) out.nodes[cpos] = KdNodeDev{0.0f, T_EMPTY};
+        const uint32_t pi = atomicAdd(&out.counters[C_PAIRS], 1u);
+        if (pi < out.cap_pairs) out.pairs[pi] = make_uint2(cheap, T_EMPTY);
+        atomicAdd(&out.counters[C_EMPTY], 1u);
+        return;
+    }
+    // leaf: the first four faces of the list, the rest is dropped (KdLeaf, js/8-kd_tree.js:1610-1617)
+    const uint32_t li = atomicAdd(&out.counters[C_LEAVES], 1u);
+    if (li >= out.cap_leaves) return;
+    const uint32_t keep = n < 4u ? n : 4u;
+    out.leaf_heap[li] = cheap;
+    out.leaf_count[li] = keep;
+    out.leaf_pos[li] = cpos;
+    for (uint32_t k = 0; k < 4u; k++) {   // (a pool that ran out is noticed by the host after this level: stay inside it)
+        const uint32_t src = child_start[t] + k;
+        out.leaf_faces[4 * (size_t)li + k] = (k < keep && src < pool_cap) ? next_face[src] : NONE;
+    }
+}
+
+__device__ __forceinline__ uint32_t code_of_heap(uint32_t heap) {
+    const uint32_t x = heap + 1u;
+    const int depth = 31 - __clz((int)x);
+    return (x ^ (1u << depth)) << (PATH_BITS - depth);
+}
+
+// Leaves are numbered in the reference's creation order: depth first, upper child first. Of two leaves the one in
+// the upper subtree of their common ancestor comes first, i.e. the one with the larger path code (the codes are
+// prefix-free). code_count is indexed by the complement of the code, so that an exclusive sum over it runs in that order:
+// low word = faces kept by the leaves before this one (its first slot in the leaf-ordered triangle table), high word =
+// number of leaves before it (its index).
+__global__ __launch_bounds__(256) void k_kd_leaf_mark(const uint32_t *leaf_heap, const uint32_t *leaf_count, uint32_t n_leaves,
+                                                      unsigned long long *code_count) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_leaves) return;
+    const uint32_t key = ~code_of_heap(leaf_heap[i]) & (CODES - 1u);
+    code_count[key] = (unsigned long long)leaf_count[i] | (1ull << 32);
+}
+
+__global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap, const uint32_t *leaf_count, const uint32_t *leaf_pos,
+                                                      const uint32_t *leaf_faces, uint32_t n_leaves,
+                                                      const unsigned long long *code_scan, const TriDev *tris, KdNodeDev *nodes,
+                                                      uint32_t node_cap, TriDev *ltris, uint32_t cap_slots, uint32_t *path_slot,
+                                                      int32_t *leaves, uint2 *pairs, uint32_t cap_pairs, uint32_t *counters) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_leaves) return;
+    const uint32_t heap = leaf_heap[i], code = code_of_heap(heap), cnt = leaf_count[i];
+    const unsigned long long x = code_scan[~code & (CODES - 1u)];
+    const uint32_t first = (uint32_t)x, number = (uint32_t)(x >> 32);
+    if (leaf_pos[i] < node_cap) nodes[leaf_pos[i]] = KdNodeDev{0.0f, T_LEAF | (cnt << LEAF_COUNT_SHIFT) | first};
+    path_slot[code] = first;
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t f = leaf_faces[4 * (size_t)i + k];
+        leaves[4 * (size_t)number + k] = k < cnt ? (int32_t)f : -1;
+        if (k < cnt && first + k < cap_slots) {
+            TriDev t = tris[f];
+            t.code = code;
+            ltris[first + k] = t;
+        }
+    }
+    const uint32_t pi = atomicAdd(&counters[C_PAIRS], 1u);
+    if (pi < cap_pairs) pairs[pi] = make_uint2(heap, T_LEAF | number);
+}
+
+#define KCK(call)                                                              \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) {                                                \
+            err = std::string(#call) + ": " + hipGetErrorString(e_);           \
+            return -1;                                                         \
+        }                                                                      \
+    } while (0)
+
+template <class T>
+int grow(T *&p, size_t n, std::string &err) {
+    if (p) KCK(hipFree(p));
+    p = nullptr;
+    KCK(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)));
+    return 0;
+}
+
+inline dim3 blocks_for(uint64_t n) { return dim3((unsigned)std::max<uint64_t>((n + 255) / 256, 1)); }
+
+}  // namespace
+
+GpuKdBuilder::~GpuKdBuilder() { release(); }
+
+void GpuKdBuilder::release() {
+    void *ptrs[] = {d_verts, d_faces, d_face_mat, pool_face[0], pool_face[1], pool_owner[0], pool_owner[1], flags, scanned,
+                    child_flag, child_scan, child_count, child_start, owner_map, code_count, code_scan, leaf_heap, leaf_count,
+                    leaf_pos, leaf_faces, counters, scan_tmp, tree.nodes, tree.tris, tree.ltris, tree.path_slot, tree.pairs,
+                    tree.leaves};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto &l : lv)
+        for (void *p : {(void *)l.blo, (void *)l.bhi, (void *)l.flo, (void *)l.fhi, (void *)l.heap, (void *)l.start, (void *)l.count, (void *)l.pos})
+            if (p) (void)hipFree(p);
+    if (h_counters) (void)hipHostFree(h_counters);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+}
+
+// buffers that depend on the mesh size only; the lists are sized generously and checked after every level
+int GpuKdBuilder::reserve(int64_t n_verts, int64_t n_faces, std::string &err) {
+    if (!ev0) { KCK(hipEventCreate(&ev0)); KCK(hipEventCreate(&ev1)); }
+    if (!counters) {
+        KCK(hipMalloc((void **)&counters, (C_WORDS + 12) * sizeof(uint32_t)));   // counters, then six 64-bit box keys
+        KCK(hipHostMalloc((void **)&h_counters, (C_WORDS + 12) * sizeof(uint32_t)));
+    }
+    if ((size_t)n_verts > cap_verts) { if (grow(d_verts, (size_t)n_verts * 3, err)) return -1; cap_verts = (size_t)n_verts; }
+    if ((size_t)n_faces > cap_faces) {
+        if (grow(d_faces, (size_t)n_faces * 3, err) || grow(d_face_mat, (size_t)n_faces, err)) return -1;
+        cap_faces = (size_t)n_faces;
+    }
+    if ((size_t)n_faces > cap_tris) { if (grow(tree.tris, (size_t)n_faces, err)) return -1; cap_tris = (uint32_t)n_faces; }
+    const uint32_t want_pool = (uint32_t)std::min<int64_t>(std::max<int64_t>(n_faces * 16, 1 << 20) * (int64_t)grow_pool, 0x3fffffff);
+    if (want_pool > cap_pool) {
+        for (int i = 0; i < 2; i++)
+            if (grow(pool_face[i], want_pool, err) || grow(pool_owner[i], want_pool, err)) return -1;
+        if (grow(flags, 2 * (size_t)want_pool + 1, err) || grow(scanned, 2 * (size_t)want_pool + 1, err)) return -1;
+        cap_pool = want_pool;
+    }
+    const uint32_t want_nodes = (uint32_t)std::min<int64_t>(std::max<int64_t>(n_faces * 4, 1 << 16) * (int64_t)grow_nodes, 1 << 26);
+    if (want_nodes > cap_level_nodes) {
+        for (auto &l : lv)
+            if (grow(l.blo, 3 * (size_t)want_nodes, err) || grow(l.bhi, 3 * (size_t)want_nodes, err) ||
+                grow(l.flo, 3 * (size_t)want_nodes, err) || grow(l.fhi, 3 * (size_t)want_nodes, err) ||
+                grow(l.heap, want_nodes, err) || grow(l.start, want_nodes, err) || grow(l.count, want_nodes, err) ||
+                grow(l.pos, want_nodes, err))
+                return -1;
+        const size_t nc = 2 * (size_t)want_nodes + 1;
+        if (grow(child_flag, nc, err) || grow(child_scan, nc, err) || grow(child_count, nc, err) || grow(child_start, nc, err) ||
+            grow(owner_map, nc, err))
+            return -1;
+        cap_level_nodes = want_nodes;
+    }
+    const uint32_t want_leaves = (uint32_t)std::min<int64_t>(std::max<int64_t>(n_faces * 8, 1 << 16) * (int64_t)grow_leaves, 1 << 27);
+    if (want_leaves > cap_leaves) {
+        if (grow(leaf_heap, want_leaves, err) || grow(leaf_count, want_leaves, err) || grow(leaf_pos, want_leaves, err) ||
+            grow(leaf_faces, 4 * (size_t)want_leaves, err) || grow(tree.leaves, 4 * (size_t)want_leaves, err) ||
+            grow(tree.ltris, 4 * (size_t)want_leaves, err))
+            return -1;
+        cap_leaves = want_leaves;
+        cap_leaf_table = want_leaves;
+        cap_slots = 4 * want_leaves;
+    }
+    const uint32_t want_pairs = 4 * want_leaves;
+    if (want_pairs > cap_pairs) { if (grow(tree.pairs, want_pairs, err)) return -1; cap_pairs = want_pairs; }
+    if (!code_count) {
+        if (grow(code_count, (size_t)CODES + 1, err) || grow(code_scan, (size_t)CODES + 1, err) || grow(tree.path_slot, (size_t)CODES, err)) return -1;
+    }
+    // temporary storage of the scans: the largest of the three uses
+    size_t need = 0, b = 0;
+    KCK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, flags, scanned, (int)(2 * (size_t)cap_pool + 1)));
+    need = std::max(need, b);
+    KCK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, child_flag, child_scan, (int)(2 * (size_t)cap_level_nodes + 1)));
+    need = std::max(need, b);
+    KCK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, code_count, code_scan, (int)(CODES + 1)));
+    need = std::max(need, b);
+    if (need > scan_tmp_bytes) {
+        if (scan_tmp) KCK(hipFree(scan_tmp));
+        scan_tmp = nullptr;
+        KCK(hipMalloc(&scan_tmp, need));
+        scan_tmp_bytes = need;
+    }
+    return 0;
+}
+
+// the node array grows by whole blocks; what is there already is kept
+int GpuKdBuilder::ensure_nodes(hipStream_t s, uint32_t slots, std::string &err) {
+    if (slots <= cap_node_slots) return 0;
+    const uint32_t want = std::max<uint32_t>(slots + slots / 2, 1u << 16);
+    KdNodeDev *nn = nullptr;
+    KCK(hipMalloc((void **)&nn, (size_t)want * sizeof(KdNodeDev)));
+    if (tree.nodes) {
+        KCK(hipMemcpyAsync(nn, tree.nodes, (size_t)cap_node_slots * sizeof(KdNodeDev), hipMemcpyDeviceToDevice, s));
+        KCK(hipStreamSynchronize(s));
+        KCK(hipFree(tree.nodes));
+    }
+    tree.nodes = nn;
+    cap_node_slots = want;
+    return 0;
+}
+
+// The lists are sized from the face count; a mesh whose faces spread over many more cells than usual asks for more:
+// the list that ran out is enlarged and the build starts over.
+int GpuKdBuilder::build(hipStream_t s, const double *verts, int64_t n_verts, const uint32_t *faces, const int32_t *face_mat,
+                        int64_t n_faces, int max_depth, double infinity, std::string &err) {
+    for (int attempt = 0; attempt < 12; attempt++) {
+        const int r = build_once(s, verts, n_verts, faces, face_mat, n_faces, max_depth, infinity, err);
+        if (r <= 0) return r;
+    }
+    err = "device k-d build: lists still too small after repeated growth (" + err + ")";
+    return -1;
+}
+
+int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts, const uint32_t *faces, const int32_t *face_mat,
+                             int64_t n_faces, int max_depth, double infinity, std::string &err) {
+    if (max_depth > 24) max_depth = 24;
+    if (n_faces <= 4 || max_depth <= 1) { err = "device k-d build needs more than four faces and a depth limit above 1"; return -1; }
+    if (n_faces > 0x0fffffff) { err = "device k-d build: too many faces"; return -1; }
+    if (reserve(n_verts, n_faces, err)) return -1;
+    const uint32_t nf = (uint32_t)n_faces;
+    KCK(hipMemcpyAsync(d_verts, verts, (size_t)n_verts * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    KCK(hipMemcpyAsync(d_faces, faces, (size_t)n_faces * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    KCK(hipMemcpyAsync(d_face_mat, face_mat, (size_t)n_faces * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    KCK(hipEventRecord(ev0, s));
+
+    // counters and the root box
+    unsigned long long *box_keys = (unsigned long long *)(counters + C_WORDS);
+    {
+        memset(h_counters, 0, (C_WORDS + 12) * sizeof(uint32_t));
+        unsigned long long *hk = (unsigned long long *)(h_counters + C_WORDS);
+        for (int k = 0; k < 3; k++) { hk[k] = host_order_key(infinity); hk[3 + k] = host_order_key(-infinity); }
+        KCK(hipMemcpyAsync(counters, h_counters, (C_WORDS + 12) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_kd_root_box, blocks_for(nf), dim3(256), 0, s, d_verts, d_faces, nf, box_keys);
+        hipLaunchKernelGGL(k_kd_make_tris, blocks_for(nf), dim3(256), 0, s, d_verts, d_faces, d_face_mat, nf, tree.tris);
+        KCK(hipMemcpyAsync(h_counters, counters, (C_WORDS + 12) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        KCK(hipStreamSynchronize(s));
+        for (int k = 0; k < 6; k++) tree.root_box[k] = key_value(hk[k]);
+    }
+
+    // level 0: the root owns every face, in index order
+    Nodes cur{lv[0].blo, lv[0].bhi, lv[0].flo, lv[0].fhi, lv[0].heap, lv[0].start, lv[0].count, lv[0].pos};
+    Nodes nxt{lv[1].blo, lv[1].bhi, lv[1].flo, lv[1].fhi, lv[1].heap, lv[1].start, lv[1].count, lv[1].pos};
+    {
+        double bd[6];
+        float bf[6];
+        for (int k = 0; k < 6; k++) { bd[k] = tree.root_box[k]; bf[k] = (float)tree.root_box[k]; }
+        const uint32_t zero = 0, cnt = nf;
+        KCK(hipMemcpyAsync(cur.blo, bd, 3 * sizeof(double), hipMemcpyHostToDevice, s));
+        KCK(hipMemcpyAsync(cur.bhi, bd + 3, 3 * sizeof(double), hipMemcpyHostToDevice, s));
+        KCK(hipMemcpyAsync(cur.flo, bf, 3 * sizeof(float), hipMemcpyHostToDevice, s));
+        KCK(hipMemcpyAsync(cur.fhi, bf + 3, 3 * sizeof(float), hipMemcpyHostToDevice, s));
+        KCK(hipMemcpyAsync(cur.heap, &zero, 4, hipMemcpyHostToDevice, s));
+        KCK(hipMemcpyAsync(cur.start, &zero, 4, hipMemcpyHostToDevice, s));
+        KCK(hipMemcpyAsync(cur.count, &cnt, 4, hipMemcpyHostToDevice, s));
+        KCK(hipMemcpyAsync(cur.pos, &zero, 4, hipMemcpyHostToDevice, s));
+        KCK(hipStreamSynchronize(s));   // the sources are locals
+        hipLaunchKernelGGL(k_kd_iota, blocks_for(nf), dim3(256), 0, s, pool_face[0], nf);
+        KCK(hipMemsetAsync(pool_owner[0], 0, (size_t)nf * sizeof(uint32_t), s));
+    }
+    uint32_t n_active = 1, n_pool = nf, used_slots = 16;   // the root keeps a 16-slot line of its own
+    if (ensure_nodes(s, used_slots, err)) return -1;
+    KCK(hipMemsetAsync(tree.nodes, 0, 16 * sizeof(KdNodeDev), s));
+    int side = 0;
+    tree.n_internal = 0;
+    tree.depth = 1;
+    EmitOut out{tree.nodes, cap_node_slots, tree.pairs, cap_pairs, leaf_heap, leaf_count, leaf_pos, leaf_faces, cap_leaves, counters};
+
+    for (int d = 0; n_active > 0; d++) {   // d = depth of the active nodes, root = 0 (the reference counts from 1)
+        const int axis = d % 3;            // js/8-kd_tree.js:1689-1702: x, y, z from the root down
+        const bool first_level = (d == 0);
+        const uint32_t *omap = first_level ? nullptr : owner_map;
+        const size_t n_flags = 2 * (size_t)n_pool + 1;
+        KCK(hipMemsetAsync(flags, 0, n_flags * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_kd_test, blocks_for(n_pool), dim3(256), 0, s, d_verts, d_faces, pool_face[side], pool_owner[side], omap,
+                           n_pool, cur, axis, flags);
+        size_t tmp = scan_tmp_bytes;
+        KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, flags, scanned, (int)n_flags, s));
+        hipLaunchKernelGGL(k_kd_scatter, blocks_for(n_pool), dim3(256), 0, s, pool_face[side], pool_owner[side], omap, n_pool, cur,
+                           flags, scanned, cap_pool, pool_face[side ^ 1], pool_owner[side ^ 1]);
+        hipLaunchKernelGGL(k_kd_classify, blocks_for(2 * (uint64_t)n_active), dim3(256), 0, s, cur, n_active, scanned, d + 2, max_depth,
+                           child_start, child_count, child_flag);
+        const size_t n_child = 2 * (size_t)n_active + 1;
+        KCK(hipMemsetAsync(child_flag + 2 * (size_t)n_active, 0, sizeof(uint32_t), s));
+        tmp = scan_tmp_bytes;
+        KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, child_flag, child_scan, (int)n_child, s));
+        // the children of the root and of every third level below it open new 16-slot blocks
+        const bool opens_block = (d % 3 == 0);
+        uint32_t block_base = 0;
+        if (opens_block) {
+            block_base = used_slots;
+            if ((uint64_t)used_slots + 16ull * n_active > 0x0fffffffull) { err = "device k-d build: node array too large"; return -1; }
+            used_slots += 16u * n_active;
+            if (ensure_nodes(s, used_slots, err)) return -1;
+            KCK(hipMemsetAsync(tree.nodes + block_base, 0, (size_t)16 * n_active * sizeof(KdNodeDev), s));
+            out.nodes = tree.nodes;
+            out.node_cap = cap_node_slots;
+        }
+        // the emit kernel writes owner_map, which k_kd_test / k_kd_scatter of this level read: they are done (same stream)
+        hipLaunchKernelGGL(k_kd_emit, blocks_for(2 * (uint64_t)n_active), dim3(256), 0, s, cur, nxt, n_active, cap_level_nodes, axis,
+                           opens_block ? 1 : 0, block_base, child_start, child_count, child_flag, child_scan, pool_face[side ^ 1],
+                           cap_pool, owner_map, out);
+        KCK(hipGetLastError());
+        uint32_t next_pool = 0, next_active = 0;
+        KCK(hipMemcpyAsync(&h_counters[C_WORDS + 12 - 2], scanned + 2 * (size_t)n_pool, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        KCK(hipMemcpyAsync(&h_counters[C_WORDS + 12 - 1], child_scan + 2 * (size_t)n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        KCK(hipStreamSynchronize(s));
+        next_pool = h_counters[C_WORDS + 12 - 2];
+        next_active = h_counters[C_WORDS + 12 - 1];
+        if (next_pool > cap_pool) { err = "face pool too small"; grow_pool *= 2; return 1; }
+        if (next_active > cap_level_nodes) { err = "level node arrays too small"; grow_nodes *= 2; return 1; }
+        tree.n_internal += n_active;
+        tree.depth = d + 2;
+        n_pool = next_pool;
+        n_active = next_active;
+        side ^= 1;
+        std::swap(cur, nxt);
+    }
+
+    // leaves: numbering, leaf-ordered triangles, path table, reference leaf table
+    KCK(hipMemcpyAsync(h_counters, counters, C_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    KCK(hipStreamSynchronize(s));
+    const uint32_t n_leaves = h_counters[C_LEAVES];
+    if (n_leaves > cap_leaves) { err = "leaf list too small"; grow_leaves *= 2; return 1; }
+    KCK(hipMemsetAsync(code_count, 0, ((size_t)CODES + 1) * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_kd_leaf_mark, blocks_for(n_leaves), dim3(256), 0, s, leaf_heap, leaf_count, n_leaves, code_count);
+    size_t tmp = scan_tmp_bytes;
+    KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, code_count, code_scan, (int)(CODES + 1), s));
+    hipLaunchKernelGGL(k_kd_leaf_emit, blocks_for(n_leaves), dim3(256), 0, s, leaf_heap, leaf_count, leaf_pos, leaf_faces, n_leaves,
+                       code_scan, tree.tris, tree.nodes, cap_node_slots, tree.ltris, cap_slots, tree.path_slot, tree.leaves, tree.pairs,
+                       cap_pairs, counters);
+    KCK(hipGetLastError());
+    unsigned long long total = 0;
+    KCK(hipMemcpyAsync(&total, code_scan + CODES, sizeof total, hipMemcpyDeviceToHost, s));
+    KCK(hipMemcpyAsync(h_counters, counters, C_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    KCK(hipEventRecord(ev1, s));
+    KCK(hipStreamSynchronize(s));
+    if ((uint32_t)(total >> 32) != n_leaves) { err = "device k-d build: two leaves share a path code"; return -1; }
+    if (h_counters[C_PAIRS] > cap_pairs) { err = "node list too small"; grow_leaves *= 2; return 1; }
+    tree.n_slots = (uint32_t)total;
+    tree.n_leaves = n_leaves;
+    tree.n_leaf = n_leaves;
+    tree.n_empty = h_counters[C_EMPTY];
+    tree.n_nodes = h_counters[C_PAIRS];
+    tree.n_node_slots = used_slots;
+    float ms = 0;
+    KCK(hipEventElapsedTime(&ms, ev0, ev1));
+    tree.build_ms = ms;
+    return 0;
+}
+
+}  // namespace rt

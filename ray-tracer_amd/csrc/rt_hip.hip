@@ -13,6 +13,7 @@
 
 #include "../../include/rt_hip.h"
 #include "kd_build.h"
+#include "kd_build_gpu.h"
 #include "rt_device.h"
 #include "rt_kernels.h"
 
@@ -84,6 +85,8 @@ struct rt_ctx {
     std::vector<uint32_t> faces, face_mat;
     std::vector<TriDev> tris_host;
     KdTreeHost kd;
+    GpuKdBuilder *gpu_kd = nullptr;              // device-side builder and its tree (rt_build_kdtree_device)
+    bool kd_on_device = false;                   // the current tree is gpu_kd->tree, not `kd`
     bool kd_built = false, scene_dirty = true, mesh_dirty = true;
     SceneDev sh{};   // host mirror of the device scene header
     // device
@@ -183,6 +186,29 @@ int ensure_queues(rt_ctx *ctx, Part &P, int level, uint32_t n_rays, uint32_t n_l
     return 0;
 }
 
+// builds the tree of the current mesh on the device (kd_build_gpu.h); per-face material slots are resolved here
+int device_build(rt_ctx *ctx) {
+    auto find_mat = [&](int type, int id) -> int32_t {
+        for (size_t i = 0; i < ctx->mats_host.size(); i++)
+            if (ctx->mats_host[i].type == type && ctx->mats_host[i].id == id) return (int32_t)i;
+        return -1;
+    };
+    const size_t nf = ctx->faces.size() / 3;
+    std::vector<int32_t> slots(nf);
+    for (size_t f = 0; f < nf; f++) slots[f] = find_mat((int)ctx->face_mat[2 * f], (int)ctx->face_mat[2 * f + 1]);
+    if (!ctx->gpu_kd) ctx->gpu_kd = new GpuKdBuilder();
+    auto t0 = std::chrono::steady_clock::now();
+    std::string err;
+    if (ctx->gpu_kd->build(ctx->stream, ctx->verts.data(), (int64_t)ctx->verts.size() / 3, ctx->faces.data(), slots.data(),
+                           (int64_t)nf, ctx->cfg.max_kd_depth, (double)ctx->cfg.infinity, err)) {
+        ctx->err = "rt_build_kdtree_device: " + err;
+        return -1;
+    }
+    ctx->st.kd_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->st.kd_upload_ms = 0.0;
+    return 0;
+}
+
 int upload_scene(rt_ctx *ctx) {
     // material index per primitive / per face is resolved here: (type, id) -> slot in the table
     auto find_mat = [&](int type, int id) -> int32_t {
@@ -216,6 +242,11 @@ int upload_scene(rt_ctx *ctx) {
     if (!ctx->mats.empty()) HIPCK(hipMemcpyAsync(ctx->d_mats, ctx->mats.data(), ctx->mats.size() * sizeof(MatDev), hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->lights.empty()) HIPCK(hipMemcpyAsync(ctx->d_lights, ctx->lights.data(), ctx->lights.size() * sizeof(LightDev), hipMemcpyHostToDevice, ctx->stream));
 
+    if (ctx->mesh_dirty && ctx->kd_on_device) {
+        // the material table changed under a device-built tree: its triangles carry material slots
+        if (device_build(ctx)) return -1;
+        ctx->mesh_dirty = false;
+    }
     if (ctx->mesh_dirty) {
         // triangles: float32 narrowing of the vertices (js/8-kd_tree.js:2462-2464), edges formed in float32
         const size_t nf = ctx->faces.size() / 3;
@@ -237,7 +268,7 @@ int upload_scene(rt_ctx *ctx) {
         ctx->mesh_dirty = false;
         ctx->tree_dirty = true;
     }
-    if (ctx->tree_dirty && ctx->kd_built) {
+    if (ctx->tree_dirty && ctx->kd_built && !ctx->kd_on_device) {
         // device form of the tree: leaves name a slot range of the leaf-ordered triangle array
         auto t0 = std::chrono::steady_clock::now();
         const KdTreeHost &kd = ctx->kd;
@@ -297,13 +328,18 @@ int upload_scene(rt_ctx *ctx) {
     h.tri_eps = c.triangle_epsilon;
     if (h.render_triangles && h.use_kd) {
         if (!ctx->kd_built) return fail(ctx, "rt_trace: mesh set but rt_build_kdtree was not called");
+        const double *rb = ctx->kd_on_device ? ctx->gpu_kd->tree.root_box : ctx->kd.root_box;
         for (int k = 0; k < 3; k++) {   // uniform3fv narrowing of root.min / root.max (js/8-kd_tree.js:1114, :2519-2520)
-            h.box_lo[k] = (float)ctx->kd.root_box[k];
-            h.box_hi[k] = (float)ctx->kd.root_box[3 + k];
+            h.box_lo[k] = (float)rb[k];
+            h.box_hi[k] = (float)rb[3 + k];
         }
     }
     h.prims = ctx->d_prims; h.mats = ctx->d_mats; h.lights = ctx->d_lights; h.tris = ctx->d_tris;
     h.nodes = ctx->d_nodes; h.ltris = ctx->d_ltris; h.path_slot = ctx->d_path_slot;
+    if (ctx->kd_on_device) {
+        const GpuKdTree &t = ctx->gpu_kd->tree;
+        h.tris = t.tris; h.nodes = t.nodes; h.ltris = t.ltris; h.path_slot = t.path_slot;
+    }
     HIPCK(hipMemcpyAsync(ctx->d_scene, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
     HIPCK(hipStreamSynchronize(ctx->stream));
     ctx->scene_dirty = false;
@@ -434,6 +470,7 @@ void rt_destroy(rt_ctx *ctx) {
     if (ctx->host_only) { delete ctx; return; }
     (void)hipSetDevice(ctx->cfg.device);
     (void)hipDeviceSynchronize();
+    delete ctx->gpu_kd;
     void *ptrs[] = {ctx->d_scene, ctx->d_prims, ctx->d_mats, ctx->d_lights, ctx->d_tris, ctx->d_nodes, ctx->d_ltris,
                     ctx->d_path_first, ctx->d_path_slot, ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_canvas,
                     ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt,
@@ -524,13 +561,30 @@ int rt_set_mesh(rt_ctx *ctx, const double *verts, int32_t n_verts, const uint32_
     ctx->faces.assign(faces, faces + (size_t)n_faces * 3);
     ctx->face_mat.assign(face_mat, face_mat + (size_t)n_faces * 2);
     ctx->kd_built = false;
+    ctx->kd_on_device = false;
     ctx->mesh_dirty = true;
+    ctx->scene_dirty = true;
+    return 0;
+}
+
+int rt_build_kdtree_device(rt_ctx *ctx) {
+    if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_build_kdtree_device: host-only context (created with device = -1)");
+    // a tree of one node (at most four faces, or no depth to split in) is not worth a launch
+    if (ctx->faces.size() / 3 <= 4 || ctx->cfg.max_kd_depth <= 1) return rt_build_kdtree(ctx);
+    HIPCK(hipSetDevice(ctx->cfg.device));
+    if (device_build(ctx)) return -1;
+    ctx->kd_on_device = true;
+    ctx->kd_built = true;
+    ctx->mesh_dirty = false;
+    ctx->tree_dirty = false;
     ctx->scene_dirty = true;
     return 0;
 }
 
 int rt_build_kdtree(rt_ctx *ctx) {
     if (!ctx) return -1;
+    if (ctx->kd_on_device) { ctx->kd_on_device = false; ctx->mesh_dirty = true; }
     auto t0 = std::chrono::steady_clock::now();
     build_kdtree(ctx->verts.data(), (int64_t)ctx->verts.size() / 3, ctx->faces.data(), (int64_t)ctx->faces.size() / 3,
                  ctx->cfg.max_kd_depth, (double)ctx->cfg.infinity, 0, ctx->kd);
@@ -550,6 +604,11 @@ int rt_build_kdtree(rt_ctx *ctx) {
 int rt_kdtree_counts(rt_ctx *ctx, int64_t *n_nodes, int64_t *n_leaves) {
     if (!ctx) return -1;
     if (!ctx->kd_built) return fail(ctx, "rt_kdtree_counts: no tree built");
+    if (ctx->kd_on_device) {
+        if (n_nodes) *n_nodes = ctx->gpu_kd->tree.n_nodes;
+        if (n_leaves) *n_leaves = ctx->gpu_kd->tree.n_leaves;
+        return 0;
+    }
     if (n_nodes) *n_nodes = ctx->kd.n_nodes;
     if (n_leaves) *n_leaves = (int64_t)ctx->kd.leaves.size();
     return 0;
@@ -558,6 +617,19 @@ int rt_kdtree_counts(rt_ctx *ctx, int64_t *n_nodes, int64_t *n_leaves) {
 int rt_export_kdtree_reference(rt_ctx *ctx, uint32_t *nodes, int32_t *leaves, double root_box[6]) {
     if (!ctx) return -1;
     if (!ctx->kd_built) return fail(ctx, "rt_export_kdtree_reference: no tree built");
+    if (ctx->kd_on_device) {
+        const GpuKdTree &t = ctx->gpu_kd->tree;
+        HIPCK(hipSetDevice(ctx->cfg.device));
+        if (nodes) {   // the device lists the nodes in no particular order: ascending heap index, like the host export
+            std::vector<std::pair<uint32_t, uint32_t>> v(t.n_nodes);
+            HIPCK(hipMemcpy(v.data(), t.pairs, (size_t)t.n_nodes * sizeof(uint2), hipMemcpyDeviceToHost));
+            std::sort(v.begin(), v.end());
+            for (size_t i = 0; i < v.size(); i++) { nodes[2 * i] = v[i].first; nodes[2 * i + 1] = v[i].second; }
+        }
+        if (leaves && t.n_leaves) HIPCK(hipMemcpy(leaves, t.leaves, (size_t)t.n_leaves * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (root_box) memcpy(root_box, t.root_box, sizeof t.root_box);
+        return 0;
+    }
     if (nodes) export_reference(ctx->kd, nodes);
     if (leaves && !ctx->kd.leaves.empty()) memcpy(leaves, ctx->kd.leaves.data(), ctx->kd.leaves.size() * sizeof(KdLeafDev));
     if (root_box) memcpy(root_box, ctx->kd.root_box, sizeof ctx->kd.root_box);

@@ -1,0 +1,85 @@
+"""The device-side k-d builder (rt_build_kdtree_device) against the same pins as the host builder: the reference's
+own arrays for the four bunny resolutions (fixtures captured from the reference's JavaScript), the oracle builder on
+random meshes, and rendered frames that must not depend on where the tree was built."""
+import numpy as np
+import pytest
+
+from helpers import make_flat, manifest, model, sha
+from oracle import oracle
+from ray_tracer_amd import abi, scene
+
+pytestmark = pytest.mark.gpu
+
+MESHES = [("bun_zipper_res4.ply", "k8_res4_640x480"), ("bun_zipper_res3.ply", "k8_res3_640x480"),
+          ("bun_zipper_res2.ply", "k8_res2_640x480"), ("bun_zipper.ply", "k8_full_640x480")]
+
+
+@pytest.mark.parametrize("ply,gold", MESHES)
+def test_device_builder_bit_exact_against_reference(ply, gold):
+    m = manifest(gold)
+    sc = scene.default_scene(model(ply))
+    v, f, fm = sc.mesh_arrays()
+    rt = abi.RayTracerHIP(abi.default_config(64, 48))
+    rt.setMesh(v, f, fm)
+    rt.buildKdTree(on_device=True)
+    pairs, leaves, box = rt.exportKdTree()
+    kd = m["kd"]
+    assert sha(box) == kd["sha256"]["root_box_f64"]
+    types = pairs[:, 1] >> 30
+    assert (int((types == 1).sum()), int((types == 3).sum()), int((types == 2).sum())) == (kd["n_internal"], kd["n_leaf"], kd["n_empty"])
+    assert sha(leaves) == kd["sha256"]["leaves_i32"]
+    assert sha(pairs) == kd["sha256"]["nodes_sparse_u32"]
+    rt.close()
+
+
+def test_device_builder_random_meshes_match_oracle():
+    rng = np.random.default_rng(11)
+    rt = abi.RayTracerHIP(abi.default_config(64, 48))
+    for n_faces in (5, 6, 40, 700, 3000):
+        v = rng.uniform(-50, 50, size=(n_faces * 2, 3))
+        f = rng.integers(0, len(v), size=(n_faces, 3)).astype(np.uint32)
+        v[f[:, 1]] = v[f[:, 0]] + rng.normal(0, 2.0, size=(n_faces, 3))
+        v[f[:, 2]] = v[f[:, 0]] + rng.normal(0, 2.0, size=(n_faces, 3))
+        rt.setMesh(v, f, np.zeros((n_faces, 2), np.uint32))
+        rt.buildKdTree(on_device=True)
+        pairs, leaves, box = rt.exportKdTree()
+        op, ol, ob, _ = oracle.kd_build(v, f)
+        assert np.array_equal(ob, box), n_faces
+        assert np.array_equal(ol, leaves), n_faces
+        assert np.array_equal(op, pairs), n_faces
+    # small inputs fall through to the host builder
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float64)
+    f = np.array([[0, 1, 2], [0, 1, 3], [1, 2, 3]], np.uint32)
+    rt.setMesh(v, f, np.zeros((3, 2), np.uint32))
+    rt.buildKdTree(on_device=True)
+    pairs, leaves, _ = rt.exportKdTree()
+    assert pairs.tolist() == [[0, (3 << 30) | 0]] and leaves.tolist() == [[0, 1, 2, -1]]
+    rt.close()
+
+
+def test_frames_do_not_depend_on_where_the_tree_was_built():
+    """Same scene, tree built by the host builder and by the device builder: identical float colours, bytes, hit ids
+    and ray counts (the node layouts differ, the trees do not). Then the mesh moves and the device tree is rebuilt in
+    the same context, as a per-frame rebuild does."""
+    flat = make_flat("bun_zipper_res3.ply", 320, 240, depth=3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    outs = []
+    for dev in (False, True):
+        rt = abi.RayTracerHIP(flat.cfg)
+        rt.setScene(flat, kd_on_device=dev)
+        rt.trace()
+        outs.append((rt.readFloat(), rt.readRGBA8(), rt.readHitIds(), rt.stats().rays_total, rt.stats().shadow_rays, rt))
+    assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True)
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert outs[0][3:5] == outs[1][3:5]
+    moved = flat.verts + np.array([3.0, -2.0, 5.0])
+    for i, dev in enumerate((False, True)):
+        rt = outs[i][5]
+        rt.setMesh(moved, flat.faces, flat.face_mat)
+        rt.buildKdTree(on_device=dev)
+        rt.trace()
+    a, b = outs[0][5], outs[1][5]
+    assert np.array_equal(a.readRGBA8(), b.readRGBA8()) and np.array_equal(a.readHitIds(), b.readHitIds())
+    assert not np.array_equal(a.readRGBA8(), outs[0][1])      # the mesh did move
+    pa, la, ba = a.exportKdTree()
+    pb, lb, bb = b.exportKdTree()
+    assert np.array_equal(pa, pb) and np.array_equal(la, lb) and np.array_equal(ba, bb)
