@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=3, help="frames in flight per GPU (contexts that alternate frames); 1 = finish every frame before the next")
     ap.add_argument("--walk-waves", type=int, default=0, help="persistent walk waves per CU and context (0 = 24, or 12 when the frame is split over more than 4 GPUs)")
     ap.add_argument("--sync-job", action="store_true", help="the host-synchronised frame job (every stage of the exchange waits on the host)")
+    ap.add_argument("--kd-builder", default="host", choices=["host", "device"], help="where the k-d tree is built (same tree; the node blocks are laid out in a different order)")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (rehearsal on a one-GPU box); default LOCAL_RANK")
     args = ap.parse_args()
@@ -89,7 +90,7 @@ def main():
     rts = []
     for _ in range(n_ctx):
         r = abi.RayTracerHIP(cfg)
-        r.setScene(flat)
+        r.setScene(flat, kd_on_device=(args.kd_builder == "device"))
         waves = args.walk_waves or (24 if (n_ctx == 1 or shard_count <= 4) else 12)
         r.setOption("walk_waves_per_cu", waves)
         rts.append(r)

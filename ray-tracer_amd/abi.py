@@ -110,6 +110,14 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        # PyTorch ships its own copy of the HIP runtime. If the library pulls in the system's copy first and torch is
+        # imported later, the process holds two runtimes and torch finds no GPU: let torch load its copy first.
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("HIP library missing: %s (run __graft_entry__.build() / make -C ray-tracer_amd/csrc); "
                                "there is no CPU fallback" % LIB_PATH)

@@ -193,6 +193,8 @@ class PipelinedFrameJob:
             self.slots.append({"rt": rt, "shard": sh, "stream": st, "gathered": gathered, "busy": False, "pair": None})
         self.i = 0
         self.redone = 0
+        self.rays = 0          # rays of all completed frames (this rank's shard)
+        self.shadow_rays = 0
 
     def _post(self, slot):
         """Everything behind the trace of one frame, queued on the slot's stream."""
@@ -223,6 +225,16 @@ class PipelinedFrameJob:
             self.redone += 1
             with self.torch.cuda.stream(slot["stream"]):
                 self._post(slot)
+        st = slot["rt"].stats()
+        self.rays += int(st.rays_total)
+        self.shadow_rays += int(st.shadow_rays)
+
+    def next_context(self):
+        """The context the next step() will use, with its previous frame completed: the caller may now change its
+        scene (lights, mesh, tree) for the coming frame."""
+        slot = self.slots[self.i % len(self.slots)]
+        self._finish(slot)
+        return slot["rt"]
 
     def step(self):
         """Queues one frame on the next context, then completes the frame queued before it on the other one."""

@@ -83,3 +83,48 @@ def test_frames_do_not_depend_on_where_the_tree_was_built():
     pa, la, ba = a.exportKdTree()
     pb, lb, bb = b.exportKdTree()
     assert np.array_equal(pa, pb) and np.array_equal(la, lb) and np.array_equal(ba, bb)
+
+
+def test_animated_frames_with_rebuild_match_the_oracle():
+    """BASELINE config 5 in small: light 0 on its orbit, the mesh dragged, the tree rebuilt on the device for every
+    frame, three frames in flight on alternating contexts. Every frame must equal the oracle's render of that
+    frame's scene (the oracle builds its own tree from the moved vertices)."""
+    import copy
+    import math
+    import torch
+    from ray_tracer_amd import multi_gpu
+    flat = make_flat("bun_zipper_res4.ply", 160, 120, depth=3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    base = np.ascontiguousarray(flat.verts, np.float64)
+    rts = []
+    for _ in range(3):
+        rt = abi.RayTracerHIP(flat.cfg)
+        rt.setScene(flat, kd_on_device=True)
+        rts.append(rt)
+    job = multi_gpu.PipelinedFrameJob(rts, multi_gpu.Comm(0, 1, 0, backend=None, device="cuda:0"))
+
+    def scene_of(k):
+        t = k / 60.0
+        x = 500.0 * math.cos(2.0 * math.pi * (t % 60.0) / 60.0)
+        lights = [((x, 300.0, x - 280.0), flat.lights[0][1])] + list(flat.lights[1:])
+        a = 2.0 * math.pi * k / 240.0
+        return lights, base + np.array([12.0 * math.sin(a), 0.0, 12.0 * (math.cos(a) - 1.0)])
+
+    frames = [0, 30, 60, 90, 120, 150]
+    for k in frames:
+        lights, verts = scene_of(k)
+        rt = job.next_context()
+        rt.setLights(lights, flat.n_lights_loop)
+        rt.setMesh(verts, flat.faces, flat.face_mat)
+        rt.buildKdTree(on_device=True)
+        job.step()
+    job.flush()
+    torch.cuda.synchronize()
+    for slot, k in ((0, frames[3]), (1, frames[4]), (2, frames[5])):   # the last frame of each context
+        f = copy.copy(flat)
+        f.lights, f.verts = scene_of(k)
+        want_f, want_8, want_id, cn = oracle.OracleRenderer(f).trace(threads=16)
+        rt = rts[slot]
+        assert np.array_equal(rt.readHitIds(), want_id), k
+        assert np.array_equal(rt.readRGBA8(), want_8), k
+        assert np.array_equal(rt.readFloat(), want_f, equal_nan=True), k
+        assert rt.stats().rays_total == cn.rays
