@@ -218,7 +218,31 @@ static napi_value js_set_mesh(napi_env env, napi_callback_info info) {
         return NULL;                                                     \
     }
 CALL0(js_build_kdtree, rt_build_kdtree)
+CALL0(js_build_kdtree_device, rt_build_kdtree_device)
 CALL0(js_trace, rt_trace)
+CALL0(js_trace_begin, rt_trace_begin)
+
+/* rt_trace_end: true when the frame had to be traced again with larger buffers */
+static napi_value js_trace_end(napi_env env, napi_callback_info info) {
+    ARGS(1)
+    rt_ctx *ctx;
+    if (!get_ctx(env, argv[0], &ctx)) return NULL;
+    int rc = rt_trace_end(ctx);
+    if (rc < 0) return throw_rt(env, ctx, "rt_trace_end");
+    napi_value b;
+    NAPI_OK(napi_get_boolean(env, rc == 1, &b));
+    return b;
+}
+
+/* root.min, root.max of the current tree into a Float64Array(6), without exporting the tree */
+static napi_value js_kd_root_box(napi_env env, napi_callback_info info) {
+    ARGS(2)
+    rt_ctx *ctx; void *b; size_t nb;
+    if (!get_ctx(env, argv[0], &ctx) || !get_bytes(env, argv[1], &b, &nb)) return NULL;
+    if (nb != 48) { napi_throw_type_error(env, NULL, "kdRootBox: expected Float64Array(6)"); return NULL; }
+    if (rt_export_kdtree_reference(ctx, NULL, NULL, (double *)b) != 0) return throw_rt(env, ctx, "rt_export_kdtree_reference");
+    return NULL;
+}
 
 static napi_value js_kdtree_counts(napi_env env, napi_callback_info info) {
     ARGS(1)
@@ -326,8 +350,9 @@ static napi_value init(napi_env env, napi_value exports) {
         {"structSizes", js_struct_sizes}, {"defaultConfig", js_default_config}, {"create", js_create}, {"destroy", js_destroy},
         {"setPrimitives", js_set_primitives}, {"setMaterials", js_set_materials}, {"setLights", js_set_lights},
         {"setGlobals", js_set_globals}, {"setCamera", js_set_camera}, {"setMesh", js_set_mesh},
-        {"buildKdTree", js_build_kdtree}, {"kdtreeCounts", js_kdtree_counts}, {"exportKdTree", js_export_kdtree},
-        {"trace", js_trace}, {"readFloat", js_read_float}, {"readRGBA8", js_read_rgba8}, {"readHitIds", js_read_hit_ids},
+        {"buildKdTree", js_build_kdtree}, {"buildKdTreeDevice", js_build_kdtree_device}, {"kdtreeCounts", js_kdtree_counts},
+        {"exportKdTree", js_export_kdtree}, {"kdRootBox", js_kd_root_box},
+        {"trace", js_trace}, {"traceBegin", js_trace_begin}, {"traceEnd", js_trace_end}, {"readFloat", js_read_float}, {"readRGBA8", js_read_rgba8}, {"readHitIds", js_read_hit_ids},
         {"tone", js_tone}, {"present", js_present}, {"stats", js_stats},
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; i++) {

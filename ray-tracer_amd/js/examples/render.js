@@ -3,6 +3,7 @@
 // target and of the presented canvas, Lbar, sf, ray counts, timings). Optional: --ppm out.ppm writes the canvas.
 //   node render.js [--scene file.js] [--model models/bun_zipper_res4.ply] [--width W --height H] [--depth D]
 //                  [--ss S] [--time T] [--tr 0|1] [--frames N] [--mesh-material ka,kd,ks,ke,kReflect,kRefract,ior]
+//                  [--kd-builder host|device] [--split 1: update() as updateBegin() + updateEnd()]
 const fs = require('fs');
 const path = require('path');
 const crypto = require('crypto');
@@ -13,7 +14,7 @@ const opts = {
     WIDTH: parseInt(arg('width', '640'), 10), HEIGHT: parseInt(arg('height', '480'), 10),
     MAX_RECURSION_DEPTH: parseInt(arg('depth', '1'), 10), SUPERSAMPLING: parseInt(arg('ss', '1'), 10),
     TONE_REPRODUCTION_METHOD: parseInt(arg('tr', '0'), 10), MODEL_FILE_NAME: arg('model', 'models/bun_zipper_res4.ply'),
-    DEVICE: parseInt(arg('device', '0'), 10),
+    DEVICE: parseInt(arg('device', '0'), 10), KD_BUILDER: arg('kd-builder', 'host'),
 };
 const mm = arg('mesh-material', null);
 if (mm) opts.MESH_MATERIAL = mm.split(',').map(parseFloat);
@@ -33,7 +34,8 @@ const sha = (u8) => crypto.createHash('sha256').update(Buffer.from(u8.buffer, u8
     const t0 = process.hrtime.bigint();
     for (let f = 0; f < frames; f++) {
         G.animate(scene, time + f / 60);
-        tracer.update(time + f / 60);
+        if (arg('split', '0') === '1') { tracer.updateBegin(time + f / 60); tracer.updateEnd(); }
+        else tracer.update(time + f / 60);
         canvas = tracer.render();
     }
     const ms = Number(process.hrtime.bigint() - t0) / 1e6 / frames;

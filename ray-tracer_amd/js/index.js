@@ -30,7 +30,7 @@ const DEFAULTS = {
     WIDTH: 640, HEIGHT: 480,
     // not in the reference: HIP device (-1 = host-only context), image sharding, index rebasing for scenes with
     // more than one mesh, seconds between k-d rebuilds
-    DEVICE: 0, SHARD_INDEX: 0, SHARD_COUNT: 1, PARTS: 0, REBASE_MESH_INDICES: false, KD_REBUILD_INTERVAL: 0.30,
+    DEVICE: 0, SHARD_INDEX: 0, SHARD_COUNT: 1, PARTS: 0, REBASE_MESH_INDICES: false, KD_REBUILD_INTERVAL: 0.30, KD_BUILDER: 'host',
     ASSET_ROOT: path.join(__dirname, '..', '..', 'assets'),
 };
 

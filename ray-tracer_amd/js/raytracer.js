@@ -148,7 +148,8 @@ function makeRayTracer(G, THREE, api) {
             const k = this._meshKey;
             if (!(k && same(verts, k.verts) && same(faces, k.faces) && same(mats, k.mats))) {
                 addon.setMesh(this.ctx, verts, faces, mats);
-                if (G.USE_KD_TREE && gf.length > 0) addon.buildKdTree(this.ctx);
+                // KD_BUILDER 'device': the same tree built on the GPU (rt_build_kdtree_device), for geometry that moves
+                if (G.USE_KD_TREE && gf.length > 0) (G.KD_BUILDER === 'device' ? addon.buildKdTreeDevice : addon.buildKdTree)(this.ctx);
                 this._meshKey = { verts, faces, mats };
                 this.startTime = time;
             }
@@ -170,6 +171,19 @@ function makeRayTracer(G, THREE, api) {
         update(time) {
             this.prepare(time);
             addon.trace(this.ctx);
+            const t = addon.tone(this.ctx);
+            this.Lbar = t[0];
+            this.sf = t[1];
+        }
+
+        // update() in two halves (rt_trace_begin / rt_trace_end): updateBegin queues the frame on the GPU and returns,
+        // so the caller can prepare the next frame of another RayTracer meanwhile; updateEnd waits for it
+        updateBegin(time) {
+            this.prepare(time);
+            addon.traceBegin(this.ctx);
+        }
+        updateEnd() {
+            addon.traceEnd(this.ctx);   // a repeated trace (buffers grew) is complete when this returns
             const t = addon.tone(this.ctx);
             this.Lbar = t[0];
             this.sf = t[1];
@@ -197,7 +211,7 @@ function makeRayTracer(G, THREE, api) {
             addon.readHitIds(this.ctx, out, out.byteLength);
             return out;
         }
-        exportKdBox() { return this.exportKdTree().box; }
+        exportKdBox() { const box = new Float64Array(6); addon.kdRootBox(this.ctx, box); return box; }
         exportKdTree() {
             const [nn, nl] = addon.kdtreeCounts(this.ctx);
             const nodes = new Uint32Array(nn * 2), leaves = new Int32Array(nl * 4), box = new Float64Array(6);

@@ -73,8 +73,11 @@ console.log(JSON.stringify({msgs, traceErr}));
 def test_js_render_equals_python_binding():
     from ray_tracer_amd import abi
     mm = (0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9)
-    out = run_node([os.path.join(JS, "examples", "render.js"), "--width", "640", "--height", "480", "--depth", "5",
-                    "--mesh-material", ",".join(str(v) for v in mm)])
+    args = [os.path.join(JS, "examples", "render.js"), "--width", "640", "--height", "480", "--depth", "5",
+            "--mesh-material", ",".join(str(v) for v in mm)]
+    out = run_node(args)
+    # the same frame with the tree built on the device and update() split into its two halves
+    out_dev = run_node(args + ["--kd-builder", "device", "--split", "1", "--frames", "2", "--time", str(-1.0 / 60)])
     flat = make_flat("bun_zipper_res4.ply", 640, 480, depth=5, mesh_material=mm)
     rt = abi.RayTracerHIP(flat.cfg)
     rt.setScene(flat)
@@ -86,4 +89,6 @@ def test_js_render_equals_python_binding():
     assert out["canvas_sha256"] == hashlib.sha256(np.ascontiguousarray(canvas).tobytes()).hexdigest()
     assert out["Lbar"] == Lbar and out["sf"] == sf
     assert out["rays"] == rt.stats().rays_total
+    for k in ("rgba8_sha256", "canvas_sha256", "Lbar", "sf", "rays"):
+        assert out_dev[k] == out[k], k
     rt.close()
