@@ -240,7 +240,9 @@ def main():
             table.append({"kernel": prof_name[k], "launches_per_frame": int(launches[k]), "avg_launch_ms": tot_ms[k] / launches[k],
                           "algorithmic_bytes_per_launch": b, "achieved_GBs": b / dur_s / 1e9,
                           "valu_tflops": per_stage_flops[k] / launches[k] / dur_s / 1e12,
-                          "traffic": digest.get(prof_name[k], {}).get("hbm_bytes_per_launch") if world == 1 else None})
+                          "traffic": digest.get(prof_name[k], {}).get("hbm_bytes_per_launch") if world == 1 else None,
+                          "valu_issue_frac_profiled": digest.get(prof_name[k], {}).get("valu_issue_frac"),
+                          "l2_hit_profiled": digest.get(prof_name[k], {}).get("l2_hit")})
         d = next(t for t in table if t["kernel"] == prof_name[dom])
         out["roofline"] = {
             "bound": "hbm", "kernel": d["kernel"], "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -248,7 +250,8 @@ def main():
             "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
             "launches_per_frame": d["launches_per_frame"],
             "valu_tflops": d["valu_tflops"], "valu_frac": d["valu_tflops"] / FP32_PEAK_TFLOPS,
-            "note": "one k_kd_walk launch per pipeline step walks the closest-hit rays of a ray-tree level together with the shadow rays of the previous one; algorithmic bytes = the reference restart traversal's fetches for the same rays (8 B per descent step, 16 B per leaf visit), counted by the instrumented oracle over the same frame; the scene (about 20 MB) stays in L2 / Infinity Cache, so this walk is bound by dependent-gather latency and instruction issue, not by HBM or MFMA; `traffic` is HBM bytes per launch from the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE), mostly the leaf records written",
+            "valu_issue_frac_profiled": d["valu_issue_frac_profiled"], "l2_hit_profiled": d["l2_hit_profiled"],
+            "note": "one k_kd_walk launch per pipeline step walks the closest-hit rays of a ray-tree level together with the shadow rays of the previous one; algorithmic bytes = the reference restart traversal's fetches for the same rays (8 B per descent step, 16 B per leaf visit), counted by the instrumented oracle over the same frame; the kernel keeps a stack where the reference restarts from the root for every cell, so it moves far fewer bytes than that and the figure can exceed the HBM peak; the scene (about 20 MB) stays in L2 / Infinity Cache, so this walk is bound by vector instruction issue (valu_issue_frac_profiled: wave64 vector instructions per cycle and CU, peak 1, from the committed PMC pass) and dependent-gather latency, not by HBM or MFMA; `traffic` is HBM bytes per launch from the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE), mostly the leaf records written",
         }
         out["kernels"] = table
         out["algorithmic_frame"] = {k: v * scale * world for k, v in cn.algorithmic(None).items()}

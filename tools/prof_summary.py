@@ -82,6 +82,13 @@ for k in sorted(acc, key=lambda k: -acc[k].get("SQ_BUSY_CYCLES", 0)):
         d["wave_cycles_issue_stall"] = g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")
         d["wave_cycles_active"] = g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES")
         print("   -> wave cycles: waiting %.3f  issue-stalled %.3f  issuing %.3f" % (d["wave_cycles_wait"], d["wave_cycles_issue_stall"], d["wave_cycles_active"]))
+    if g("GRBM_GUI_ACTIVE") and g("SQ_INSTS_VALU"):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; a CU (four 16-lane SIMDs) issues at most one wave64 vector
+        # instruction per cycle, so 256 per cycle for the chip
+        cycles = g("GRBM_GUI_ACTIVE") / 8.0
+        d["valu_issue_frac"] = g("SQ_INSTS_VALU") / (cycles * 256.0)
+        d["salu_per_cycle_cu"] = g("SQ_INSTS_SALU") / (cycles * 256.0)
+        print("   -> vector instructions issued per cycle and CU = %.3f of 1.0 (scalar: %.3f)" % (d["valu_issue_frac"], d["salu_per_cycle_cu"]))
     if g("SQ_WAVES") and g("SQ_INSTS_VALU"):
         d["insts_per_wave"] = {n: g("SQ_INSTS_" + n) / g("SQ_WAVES") for n in ("VALU", "SALU", "VMEM_RD", "LDS", "SMEM")}
     if g("TCC_HIT_sum") + g("TCC_MISS_sum"):
