@@ -292,3 +292,30 @@ def test_pipelined_job_with_device_collectives_one_rank():
             assert abs(gl - wl) <= 1e-12 * wl and np.float32(gs) == np.float32(ws)
     finally:
         comm.close()
+
+
+def test_supersampled_4k_target_ward_and_reinhard_present():
+    """A 1920x1080 canvas with SUPERSAMPLING 2 (3840x2160 render target, as the project scene is configured):
+    traced windows equal the oracle, and the present pass - 2x2 box filter, Ward and Reinhard operators - equals the
+    oracle's over the whole canvas."""
+    flat = make_flat("bun_zipper_res2.ply", 1920, 1080, depth=2, ss=2, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    rt = render_hip(flat)
+    a8, aid = rt.readRGBA8(), rt.readHitIds()
+    assert a8.shape == (2160, 3840, 4)
+    o = oracle.OracleRenderer(flat)
+    for rect in ((1900, 1000, 1996, 1064), (2000, 1900, 2096, 1964)):
+        _, w8, wid, _ = o.trace(rect=rect, threads=16, want_float=False)
+        sl = (slice(rect[1], rect[3]), slice(rect[0], rect[2]))
+        assert np.array_equal(aid[sl], wid[sl]) and np.array_equal(a8[sl], w8[sl]), rect
+    Lbar, sf = rt.tone()
+    wl, ws = o.tone(a8)
+    assert abs(Lbar - wl) <= 1e-8 * wl and np.float32(sf) == np.float32(ws)
+    ward = rt.present()
+    assert ward.shape == (1080, 1920, 4)
+    assert np.array_equal(ward, o.present(a8, wl, ws))
+    flat.cfg.tr_method = 1
+    rt2 = render_hip(flat)
+    rt2.tone()
+    reinhard = rt2.present()
+    assert np.array_equal(reinhard, oracle.OracleRenderer(flat).present(a8, wl, ws))
+    assert not np.array_equal(reinhard, ward)
