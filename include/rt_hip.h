@@ -171,7 +171,8 @@ int rt_trace(rt_ctx *ctx);
  * and run behind the trace. rt_trace_end waits for the trace and checks that every buffer was large enough (they are
  * sized from the previous frames). It returns 0 when the frame is complete, 1 when buffers had to grow and the frame
  * was traced again - it is complete now, but whatever was derived from the first attempt (tone sums, presented or
- * gathered pixels) must be redone - and a negative value on failure. rt_trace = rt_trace_begin + rt_trace_end. */
+ * gathered pixels) must be redone - and a negative value on failure. The rt_read_* calls refuse to run between the
+ * two. rt_trace = rt_trace_begin + rt_trace_end. */
 int rt_trace_begin(rt_ctx *ctx);
 int rt_trace_end(rt_ctx *ctx);
 /* float colour before clamping, 3 floats per pixel, width*S x height*S, bottom-up rows.

@@ -910,6 +910,7 @@ int rt_read_float(rt_ctx *ctx, float *rgb) {
     if (ctx->host_only) return fail(ctx, "rt_read_float: host-only context (created with device = -1)");
     if (!rgb) return fail(ctx, "rt_read_float: null buffer");
     if (!ctx->traced) return fail(ctx, "rt_read_float: nothing traced yet");
+    if (ctx->in_flight) return fail(ctx, "rt_read_float: a frame is in flight, call rt_trace_end first");
     HIPCK(hipSetDevice(ctx->cfg.device));
     HIPCK(hipMemcpy(rgb, ctx->d_fb, (size_t)ctx->g.W * ctx->g.H * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
@@ -920,6 +921,7 @@ int rt_read_rgba8(rt_ctx *ctx, uint8_t *rgba) {
     if (ctx->host_only) return fail(ctx, "rt_read_rgba8: host-only context (created with device = -1)");
     if (!rgba) return fail(ctx, "rt_read_rgba8: null buffer");
     if (!ctx->traced) return fail(ctx, "rt_read_rgba8: nothing traced yet");
+    if (ctx->in_flight) return fail(ctx, "rt_read_rgba8: a frame is in flight, call rt_trace_end first");
     HIPCK(hipSetDevice(ctx->cfg.device));
     HIPCK(hipMemcpy(rgba, ctx->d_rgba, (size_t)ctx->g.W * ctx->g.H * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -930,6 +932,7 @@ int rt_read_hit_ids(rt_ctx *ctx, int32_t *ids) {
     if (ctx->host_only) return fail(ctx, "rt_read_hit_ids: host-only context (created with device = -1)");
     if (!ids) return fail(ctx, "rt_read_hit_ids: null buffer");
     if (!ctx->traced) return fail(ctx, "rt_read_hit_ids: nothing traced yet");
+    if (ctx->in_flight) return fail(ctx, "rt_read_hit_ids: a frame is in flight, call rt_trace_end first");
     HIPCK(hipSetDevice(ctx->cfg.device));
     HIPCK(hipMemcpy(ids, ctx->d_hit, (size_t)ctx->g.W * ctx->g.H * 4, hipMemcpyDeviceToHost));
     return 0;
