@@ -96,7 +96,26 @@ def main():
         rts.append(r)
     rt = rts[0]
     setup_s = (time.perf_counter() - t0) / n_ctx
-    frame = multi_gpu.PipelinedFrameJob(rts, comm) if pipelined else multi_gpu.FrameJob(rt, comm)
+    frame = None
+    if pipelined:
+        # one complete frame through the stream-ordered job first; should it raise on any rank, every rank goes on with
+        # the host-synchronised job (the ranks agree over the host-side group)
+        failed = None
+        try:
+            if os.environ.get("RT_BENCH_FAIL_PIPELINE"):   # test hook for the fall-back below
+                raise RuntimeError("RT_BENCH_FAIL_PIPELINE is set")
+            frame = multi_gpu.PipelinedFrameJob(rts, comm)
+            frame.step()
+            frame.flush()
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            failed = e
+        if comm.any_flag(failed is not None):
+            sys.stderr.write("rank %d: pipelined frame job unavailable (%r), using the host-synchronised job\n" % (rank, failed))
+            pipelined, frame, n_ctx = False, None, 1
+            rt.setOption("walk_waves_per_cu", args.walk_waves or 24)
+    if frame is None:
+        frame = multi_gpu.FrameJob(rt, comm)
     flush = frame.flush if pipelined else (lambda: None)
 
     n_warm = max(args.warmup, n_ctx)       # the first frame of every context sizes its buffers
