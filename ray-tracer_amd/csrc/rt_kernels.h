@@ -509,33 +509,50 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
 template <bool ANY>
 __device__ __forceinline__ void test_job(const SceneDev &S, const WalkJob &J) {
     const uint32_t n_rec = min(J.cnt->rec_count[ANY ? 1 : 0], J.rec_cap);
-    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_rec; r += gridDim.x * 256) {
-        const uint2 rec = J.recs[r];
+    const uint32_t stride = gridDim.x * 256;
+    uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rec) return;
+    uint2 rec = J.recs[r];
+    for (;;) {
+        // the next record is fetched before this one is worked on, and this one's ray and first triangle before the
+        // occlusion check: the loads of a lane then overlap instead of queueing behind each other (a filler names
+        // ray 0 and slot 0, both valid addresses)
+        const uint32_t rn = r + stride;
+        const uint2 next = J.recs[rn < n_rec ? rn : r];
         const uint32_t count = rec.y >> LEAF_COUNT_SHIFT, first = rec.y & LEAF_SLOT_MASK;
-        if (count == 0u) continue;
-        uint32_t id = 0;
-        if (ANY) {
-            id = J.shq_id[rec.x];
-            if (J.shadow[id >> 5] & (1u << (id & 31u))) continue;   // already known to be occluded
-        }
         V3 ro, rd;
         load_ray(J.rays, rec.x, ro, rd);
-        unsigned long long key = ~0ull;
-        for (uint32_t k = 0; k < count; k++) {
+        const TriDev *T = S.ltris + first;
+        const V3 v0 = ld3(T->v0), e1 = ld3(T->e1), e2 = ld3(T->e2);
+        uint32_t id = 0;
+        bool skip = count == 0u;
+        if (ANY) {
+            id = J.shq_id[rec.x];
+            skip = skip || (J.shadow[id >> 5] & (1u << (id & 31u))) != 0u;   // already known to be occluded
+        }
+        if (!skip) {
+            unsigned long long key = ~0ull;
             float t;
-            if (hit_tri(S.ltris[first + k], S.tri_eps, ro, rd, t)) {
+            if (hit_tri_regs(v0, e1, e2, S.tri_eps, ro, rd, t)) {
                 // t >= 0 here, so the float bits order like the values; -0 is folded onto +0
-                const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);
-                const unsigned long long kk = ((unsigned long long)tb << 32) | (unsigned long long)k;
-                key = kk < key ? kk : key;
-                if (ANY) break;
+                key = (unsigned long long)((t == 0.0f) ? 0u : __float_as_uint(t)) << 32;
+            }
+            for (uint32_t k = 1; k < count && !(ANY && key != ~0ull); k++) {
+                if (hit_tri(T[k], S.tri_eps, ro, rd, t)) {
+                    const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);
+                    const unsigned long long kk = ((unsigned long long)tb << 32) | (unsigned long long)k;
+                    key = kk < key ? kk : key;
+                }
+            }
+            if (key != ~0ull) {   // few records hit: the rest of the key is made only here
+                if (ANY) atomicOr(&J.shadow[id >> 5], 1u << (id & 31u));
+                // low word: visit rank of this leaf for this ray (see path_code), then the face's position in the leaf
+                else atomicMin(&J.best[rec.x], key | (unsigned long long)((T->code ^ near_upper_levels(rd)) << 2));
             }
         }
-        if (key != ~0ull) {   // few records hit: the rest of the key is made only here
-            if (ANY) atomicOr(&J.shadow[id >> 5], 1u << (id & 31u));
-            // low word: visit rank of this leaf for this ray (see path_code), then the face's position in the leaf
-            else atomicMin(&J.best[rec.x], key | (unsigned long long)((S.ltris[first].code ^ near_upper_levels(rd)) << 2));
-        }
+        if (rn >= n_rec) break;
+        rec = next;
+        r = rn;
     }
 }
 
