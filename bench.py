@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--walk-waves", type=int, default=0, help="persistent walk waves per CU and context (0 = 24, or 12 when the frame is split over more than 4 GPUs)")
     ap.add_argument("--sync-job", action="store_true", help="the host-synchronised frame job (every stage of the exchange waits on the host)")
     ap.add_argument("--kd-builder", default="host", choices=["host", "device"], help="where the k-d tree is built (same tree; the node blocks are laid out in a different order)")
+    ap.add_argument("--shard", default="tiles", choices=["tiles", "frames"],
+                    help="tiles: every frame is split over the GPUs (all-reduce + gather per frame); frames: step k is traced whole by rank k mod N, no exchange")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (rehearsal on a one-GPU box); default LOCAL_RANK")
     args = ap.parse_args()
@@ -80,11 +82,13 @@ def main():
             else multi_gpu.Comm(0, 1, local, backend=None, device="cuda:%d" % local))
 
     sc = build_workload(args)
-    shard_count = args.emulate_shards if (world == 1 and args.emulate_shards > 1) else world
-    cfg = abi.default_config(args.width, args.height, depth=args.depth, shard_index=rank, shard_count=shard_count, device=local,
-                             parts=args.parts)
+    by_frames = args.shard == "frames" and world > 1
+    job_comm = multi_gpu.Comm(0, 1, local, backend=None, device="cuda:%d" % local) if by_frames else comm
+    shard_count = args.emulate_shards if (world == 1 and args.emulate_shards > 1) else (1 if by_frames else world)
+    cfg = abi.default_config(args.width, args.height, depth=args.depth, shard_index=0 if by_frames else rank, shard_count=shard_count,
+                             device=local, parts=args.parts)
     flat = abi.FlatScene(sc, cfg, scene.camera_rays(args.width, args.height))
-    pipelined = not args.sync_job and (world == 1 or args.backend == "nccl")
+    pipelined = not args.sync_job and (world == 1 or by_frames or args.backend == "nccl")
     n_ctx = max(1, args.in_flight) if pipelined else 1
     t0 = time.perf_counter()
     rts = []
@@ -104,7 +108,7 @@ def main():
         try:
             if os.environ.get("RT_BENCH_FAIL_PIPELINE"):   # test hook for the fall-back below
                 raise RuntimeError("RT_BENCH_FAIL_PIPELINE is set")
-            frame = multi_gpu.PipelinedFrameJob(rts, comm)
+            frame = multi_gpu.PipelinedFrameJob(rts, job_comm)
             frame.step()
             frame.flush()
             torch.cuda.synchronize()
@@ -115,7 +119,7 @@ def main():
             pipelined, frame, n_ctx = False, None, 1
             rt.setOption("walk_waves_per_cu", args.walk_waves or 24)
     if frame is None:
-        frame = multi_gpu.FrameJob(rt, comm)
+        frame = multi_gpu.FrameJob(rt, job_comm)
     flush = frame.flush if pipelined else (lambda: None)
 
     n_warm = max(args.warmup, n_ctx)       # the first frame of every context sizes its buffers
@@ -127,8 +131,9 @@ def main():
     lvl_ms = np.zeros(8)
     stage_ms = np.zeros((8, 7))
     trace_ms = comp_ms = tone_ms = 0.0
+    my_steps = len(range(rank, args.steps, world)) if by_frames else args.steps
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(my_steps):
         frame.step()
     flush()
     comm.barrier()
@@ -149,9 +154,12 @@ def main():
         comp_ms += st.composite_ms
         tone_ms += st.tone_ms
     st = rt.stats()
-    rays = comm.sum_int(int(st.rays_total))
-    shadow = comm.sum_int(int(st.shadow_rays))
-    per_level = [comm.sum_int(int(x)) for x in st.rays_per_level]
+    if by_frames:   # every rank traces whole frames: the per-frame counts are those of any one of them
+        rays, shadow, per_level = int(st.rays_total), int(st.shadow_rays), [int(x) for x in st.rays_per_level]
+    else:
+        rays = comm.sum_int(int(st.rays_total))
+        shadow = comm.sum_int(int(st.shadow_rays))
+        per_level = [comm.sum_int(int(x)) for x in st.rays_per_level]
     K = args.steps
     lvl_ms /= n_detail
     stage_ms /= n_detail
@@ -188,10 +196,10 @@ def main():
         "dtype": "f32",
         "data": "synthetic scene: the reference's generateScene() objects + Stanford bunny" + (" + teapot" if args.teapot else ""),
         "config": {
-            "workload": "BASELINE config 3: %s (%d faces)%s, default 8-kd_tree.js scene, reflective+transmissive mesh %s, %dx%d, depth %d, 2 lights, k-d tree, tiles sharded over %d GPU(s)"
-                        % (args.model, len(flat.faces), " + teapot.obj" if args.teapot else "", str(MESH_MATERIAL), args.width, args.height, args.depth, world),
+            "workload": "BASELINE config 3: %s (%d faces)%s, default 8-kd_tree.js scene, reflective+transmissive mesh %s, %dx%d, depth %d, 2 lights, k-d tree, %s sharded over %d GPU(s)"
+                        % (args.model, len(flat.faces), " + teapot.obj" if args.teapot else "", str(MESH_MATERIAL), args.width, args.height, args.depth, "frames" if by_frames else "tiles", world),
             "rays_per_frame": rays, "shadow_rays_per_frame": shadow, "rays_per_level": per_level[:args.depth],
-            "step": "rt_trace + luminance reduction" + (" + RCCL all-reduce + tile gather + assemble + present" if world > 1 else " + present"),
+            "step": "rt_trace + luminance reduction" + (" + RCCL all-reduce + tile gather + assemble + present" if (world > 1 and not by_frames) else " + present"),
         },
         "mshadow_rays_per_s": shadow / (dt / K) / 1e6,
         "pcie_inclusive": None if pcie_ms is None else {"ms_per_step": pcie_ms, "value": rays / (pcie_ms * 1e-3) / 1e6,
@@ -228,7 +236,8 @@ def main():
         # (8 B per descent step + 16 B per leaf visit; the triangle fetches belong to k_tri_test), counted by
         # the instrumented oracle on the sample and scaled to the frame. Duration = HIP events on the library's
         # stream around every launch (rt_stats.level_stage_ms), averaged over the launches of the timed steps.
-        scale = float(args.cpu_step ** 2) / world
+        tile_world = 1 if by_frames else world
+        scale = float(args.cpu_step ** 2) / tile_world
         D = args.depth
         n_steps = D + 1
         # per pipeline stage: reference-algorithm bytes and flops of everything that stage does in one frame
@@ -274,7 +283,7 @@ def main():
             "note": "one k_kd_walk launch per pipeline step walks the closest-hit rays of a ray-tree level together with the shadow rays of the previous one; algorithmic bytes = the reference restart traversal's fetches for the same rays (8 B per descent step, 16 B per leaf visit), counted by the instrumented oracle over the same frame; the kernel keeps a stack where the reference restarts from the root for every cell, so it moves far fewer bytes than that and the figure can exceed the HBM peak; the scene (about 20 MB) stays in L2 / Infinity Cache, so this walk is bound by vector instruction issue (valu_issue_frac_profiled: wave64 vector instructions per cycle and CU, peak 1, from the committed PMC pass) and dependent-gather latency, not by HBM or MFMA; `traffic` is HBM bytes per launch from the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE), mostly the leaf records written",
         }
         out["kernels"] = table
-        out["algorithmic_frame"] = {k: v * scale * world for k, v in cn.algorithmic(None).items()}
+        out["algorithmic_frame"] = {k: v * scale * tile_world for k, v in cn.algorithmic(None).items()}
     print(json.dumps(out))
     comm.close()
 
