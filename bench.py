@@ -97,6 +97,7 @@ def main():
         r.setScene(flat, kd_on_device=(args.kd_builder == "device"))
         waves = args.walk_waves or (24 if (n_ctx == 1 or shard_count <= 4) else 12)
         r.setOption("walk_waves_per_cu", waves)
+        r.setOption("stage_timing", 0)     # per-kernel events only on the detail frames after the timed region
         rts.append(r)
     rt = rts[0]
     setup_s = (time.perf_counter() - t0) / n_ctx
@@ -144,6 +145,7 @@ def main():
     # the timed region (with several frames in flight the kernels of different frames share the GPU)
     n_detail = min(args.steps, 5)
     rt.setOption("walk_waves_per_cu", args.walk_waves or 24)
+    rt.setOption("stage_timing", 1)
     for _ in range(n_detail):
         rt.trace()
         rt.tone()

@@ -73,6 +73,8 @@ struct rt_ctx {
     hipEvent_t ev_misc[2]{};                     // tone begin / end
     int n_cus = 256;
     int walk_waves_per_cu = RT_WALK_WAVES_PER_CU;
+    bool stage_timing = true;                    // events around every stage kernel (rt_stats.level_stage_ms)
+    bool stage_timed = false;                    // the frame in flight was queued with them
     int n_parts = 1;
     Part parts[MAX_PARTS];
     // scene (host copies)
@@ -696,18 +698,18 @@ static int launch_step(rt_ctx *ctx, Part &P, int k) {
     const dim3 test_grid((unsigned)ctx->n_cus * 32u);   // grid-stride over the records
     const bool any_walk = Wk.job[0].enabled || Wk.job[1].enabled;
     hipEvent_t *ev = P.ev[k];
-    HIPCK(hipEventRecord(ev[0], s));
+    if (ctx->stage_timing) HIPCK(hipEventRecord(ev[0], s));
     if (have_cur) hipLaunchKernelGGL(k_gen_prims, grid, dim3(BLOCK), 0, s, A);
-    HIPCK(hipEventRecord(ev[1], s));
+    if (ctx->stage_timing) HIPCK(hipEventRecord(ev[1], s));
     if (any_walk) hipLaunchKernelGGL(k_kd_walk, walk_grid, dim3(WAVE), 0, s, Wk);
-    HIPCK(hipEventRecord(ev[2], s));
+    if (ctx->stage_timing) HIPCK(hipEventRecord(ev[2], s));
     if (any_walk) hipLaunchKernelGGL(k_tri_test, test_grid, dim3(256), 0, s, Wk);
-    HIPCK(hipEventRecord(ev[3], s));
+    if (ctx->stage_timing) HIPCK(hipEventRecord(ev[3], s));
     if (have_prev) hipLaunchKernelGGL(k_shade_b, grid_prev, dim3(BLOCK), 0, s, B);
-    HIPCK(hipEventRecord(ev[4], s));
+    if (ctx->stage_timing) HIPCK(hipEventRecord(ev[4], s));
     if (have_cur) hipLaunchKernelGGL(k_shade_a, grid, dim3(BLOCK), 0, s, A);
     HIPCK(hipGetLastError());
-    HIPCK(hipEventRecord(ev[5], s));
+    if (ctx->stage_timing) HIPCK(hipEventRecord(ev[5], s));
     return 0;
 }
 
@@ -839,7 +841,7 @@ static int collect_stats(rt_ctx *ctx) {
 #endif
         }
         if (P.n0 == 0) continue;
-        for (int k = 0; k <= D && k < MAX_STEPS; k++) {
+        for (int k = 0; ctx->stage_timed && k <= D && k < MAX_STEPS; k++) {
             float ms = 0;
             for (int j = 0; j < N_STAGES; j++) {
                 HIPCK(hipEventElapsedTime(&ms, P.ev[k][j], P.ev[k][j + 1]));
@@ -865,6 +867,7 @@ int rt_trace_begin(rt_ctx *ctx) {
     if (ctx->in_flight) return fail(ctx, "rt_trace_begin: the previous frame was not finished with rt_trace_end");
     HIPCK(hipSetDevice(ctx->cfg.device));
     if (ctx->scene_dirty && upload_scene(ctx)) return -1;
+    ctx->stage_timed = ctx->stage_timing;
     for (int p = 0; p < ctx->n_parts; p++)
         if (enqueue_part(ctx, ctx->parts[p])) return -1;
     // everything queued on the main stream after this call (tone, present, a caller's exchange) follows the trace
@@ -1063,6 +1066,10 @@ int rt_stream(rt_ctx *ctx, void **stream) {
 int rt_set_option(rt_ctx *ctx, const char *name, double value) {
     if (!ctx) return -1;
     if (!name) return fail(ctx, "rt_set_option: null name");
+    if (!strcmp(name, "stage_timing")) {
+        ctx->stage_timing = value != 0.0;
+        return 0;
+    }
     if (!strcmp(name, "walk_waves_per_cu")) {
         if (!(value >= 1 && value <= 32)) return fail(ctx, "rt_set_option: walk_waves_per_cu must be in 1..32");
         ctx->walk_waves_per_cu = (int)value;

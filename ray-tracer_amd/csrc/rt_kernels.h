@@ -293,7 +293,10 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
     // 32-bit population count of a wave mask (a 64-bit count would drag 64-bit compares, which have no scalar form)
 #define COUNT_OF(mask) ((uint32_t)__builtin_popcount((uint32_t)(mask)) + (uint32_t)__builtin_popcount((uint32_t)((mask) >> 32)))
 #define RANK_IN(mask) __builtin_amdgcn_mbcnt_hi((uint32_t)((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mask), 0u))
-    uint32_t more = 1u;                      // wave-uniform: the global queue may still hold rays
+    // wave-uniform: the global queue may still hold rays for this wave. There are ceil(total / chunk) chunks, so at
+    // most that many waves can ever get one: the waves beyond that number skip the job without touching the cursor
+    uint32_t more = blockIdx.x < (total + (uint32_t)REFILL_CHUNK - 1u) / (uint32_t)REFILL_CHUNK ? 1u : 0u;
+    uint32_t last_chunk = 0u;                // wave-uniform: the wave's chunk is the last of the queue
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
     float tmin = 0.0f, tmax = 0.0f, maxDist = 0.0f;
     uint32_t ref = 0;
@@ -363,24 +366,40 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
 #endif
             } else {
                 const uint32_t rank = RANK_IN(idle);
-                const uint32_t left = chunk_end - chunk_pos;
-                uint32_t q;
-                if (left < n_idle) {
-                    // the rays left in the old chunk are taken first, the rest comes from a new chunk
-                    // (a device-scope load of the cursor before the atomic, to spare the failing atomics at the end of
-                    // the queue, measured twice as slow for the whole walk)
+                const uint32_t left = chunk_end - chunk_pos;   // rays of the wave's own chunk not handed out yet
+                uint32_t q = 0xffffffffu;
+                if (left >= n_idle) {
+                    q = chunk_pos + rank;
+                    chunk_pos += n_idle;
+                } else if (UNIFORM(last_chunk)) {
+                    // the wave holds the end of the queue: what is left goes out, and no atomic is needed to know
+                    // that nothing follows
+                    if (rank < left) q = chunk_pos + rank;
+                    chunk_pos = chunk_end;
+                    more = 0u;
+                } else {
+                    // the rays left in the old chunk are taken first, the rest comes from a new chunk.
+                    // Atomics on one address are served one at a time (about 10 ns each), so the ones that can only
+                    // fail are avoided: a wave whose index is beyond the number of chunks never asks (see `more`
+                    // above), and the wave that got the last chunk knows it. (A device-scope load of the cursor
+                    // before the atomic instead measured twice as slow for the whole walk.)
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(head, (uint32_t)REFILL_CHUNK);
                     base = UNIFORM(base);
-                    q = rank < left ? chunk_pos + rank : base + (rank - left);
-                    chunk_pos = base + (n_idle - left);
-                    chunk_end = base + (uint32_t)REFILL_CHUNK;
-                    if (base >= total) { more = 0u; chunk_pos = chunk_end = 0u; }
-                } else {
-                    q = chunk_pos + rank;
-                    chunk_pos += n_idle;
+                    if (base >= total) {
+                        if (rank < left) q = chunk_pos + rank;
+                        chunk_pos = chunk_end = 0u;
+                        more = 0u;
+                    } else {
+                        const uint32_t end = min(base + (uint32_t)REFILL_CHUNK, total);
+                        const uint32_t fresh = base + (rank - left);   // lanes served from the old chunk: unused
+                        q = rank < left ? chunk_pos + rank : (fresh < end ? fresh : 0xffffffffu);
+                        chunk_pos = min(base + (n_idle - left), end);
+                        chunk_end = end;
+                        last_chunk = base + (uint32_t)REFILL_CHUNK >= total ? 1u : 0u;
+                    }
                 }
-                if (info == 0u && q < total) {
+                if (info == 0u && q != 0xffffffffu) {
                     if (ANY) {
                         ref = q;
                         const float4 fo = J.rays[2 * (size_t)q], fd = J.rays[2 * (size_t)q + 1];
