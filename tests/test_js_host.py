@@ -92,3 +92,17 @@ def test_js_render_equals_python_binding():
     for k in ("rgba8_sha256", "canvas_sha256", "Lbar", "sf", "rays"):
         assert out_dev[k] == out[k], k
     rt.close()
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_animation_same_frames_with_either_builder():
+    """examples/animate.js: the mesh dragged with Mesh.translate, the tree rebuilt every frame, two RayTracer objects
+    alternating frames (updateBegin / updateEnd). The last canvas must not depend on where the tree was built."""
+    args = [os.path.join(JS, "examples", "animate.js"), "--width", "320", "--height", "240", "--depth", "3",
+            "--model", "models/bun_zipper_res4.ply"]
+    dev = run_node(args + ["--kd-builder", "device", "--frames", "6"])
+    host = run_node(args + ["--kd-builder", "host", "--frames", "6"])
+    assert dev["last_canvas_sha256"] == host["last_canvas_sha256"]
+    one = run_node(args + ["--kd-builder", "device", "--tracers", "1", "--frames", "7"])   # same last frame index
+    assert one["last_canvas_sha256"] == dev["last_canvas_sha256"]
