@@ -101,6 +101,8 @@ def worker(rank, world, port, out):
     Lbar, sf = job.step()
     total_px = comm.sum_int(shard.tone_partial()[1])
     tmax = comm.max_float(float(rank))
+    # a flag raised on one rank is seen by all (the pipelined job repeats a frame's exchange on every rank this way)
+    assert comm.any_flag(rank == 1) is True and comm.any_flag(False) is False
     ok_frame = True
     if rank == 0:
         ok_frame = bool(np.array_equal(shard.frame, shard.full))
