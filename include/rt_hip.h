@@ -228,7 +228,9 @@ int rt_stream(rt_ctx *ctx, void **stream);
 /* Tuning knobs by name. "walk_waves_per_cu" (1..32, default 24): persistent waves per compute unit of the k-d walk;
  * two contexts that trace concurrently on one GPU fit side by side at 12. "stage_timing" (0 / 1, default 1): HIP events
  * around every stage kernel, which fill rt_stats.level_stage_ms / stage_ms / level_kernel_ms; without them those
- * fields are zero and a frame is about forty queue entries shorter. No counterpart in the reference. */
+ * fields are zero and a frame is about forty queue entries shorter. "first_level_rays" / "first_records" (0 = default):
+ * capacity of the deeper ray-tree levels / of the leaf-record buffers on a context's first frame; later frames use what
+ * the earlier ones needed (a frame that does not fit is traced again, see rt_trace_end). No counterpart in the reference. */
 int rt_set_option(rt_ctx *ctx, const char *name, double value);
 
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);

@@ -73,6 +73,7 @@ struct rt_ctx {
     hipEvent_t ev_misc[2]{};                     // tone begin / end
     int n_cus = 256;
     int walk_waves_per_cu = RT_WALK_WAVES_PER_CU;
+    uint32_t first_level_rays = 0, first_records = 0;   // sizes of the first frame's buffers (0 = defaults), rt_set_option
     bool stage_timing = true;                    // events around every stage kernel (rt_stats.level_stage_ms)
     bool stage_timed = false;                    // the frame in flight was queued with them
     int n_parts = 1;
@@ -730,14 +731,14 @@ static int enqueue_part(rt_ctx *ctx, Part &P) {
     }
     if (ensure_level(ctx, P, 0, P.n0)) return -1;
     for (int l = 1; l < D; l++) {
-        if (P.want[l] == 0) P.want[l] = P.n0;
+        if (P.want[l] == 0) P.want[l] = ctx->first_level_rays ? ctx->first_level_rays : P.n0;
         if (ensure_level(ctx, P, l, P.want[l])) return -1;
     }
     for (int l = 0; l < D; l++)
         if (ensure_queues(ctx, P, l, P.lv[l].cap, (uint32_t)sh.n_lights)) return -1;
     if (walk)
         for (int j = 0; j < 2; j++) {
-            if (P.want_recs[j] == 0) P.want_recs[j] = std::max<size_t>((size_t)8 << 20, (size_t)P.n0 * 8);
+            if (P.want_recs[j] == 0) P.want_recs[j] = ctx->first_records ? ctx->first_records : std::max<size_t>((size_t)8 << 20, (size_t)P.n0 * 8);
             if (ensure(ctx, P.d_recs[j], P.cap_recs[j], P.want_recs[j])) return -1;
         }
     for (int k = 0; k <= D; k++)
@@ -1066,6 +1067,11 @@ int rt_stream(rt_ctx *ctx, void **stream) {
 int rt_set_option(rt_ctx *ctx, const char *name, double value) {
     if (!ctx) return -1;
     if (!name) return fail(ctx, "rt_set_option: null name");
+    if (!strcmp(name, "first_level_rays") || !strcmp(name, "first_records")) {
+        if (!(value >= 0 && value <= 2147483392.0)) return fail(ctx, "rt_set_option: capacity out of range");
+        (name[6] == 'l' ? ctx->first_level_rays : ctx->first_records) = (uint32_t)value;
+        return 0;
+    }
     if (!strcmp(name, "stage_timing")) {
         ctx->stage_timing = value != 0.0;
         return 0;

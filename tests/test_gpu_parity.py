@@ -319,3 +319,24 @@ def test_supersampled_4k_target_ward_and_reinhard_present():
     reinhard = rt2.present()
     assert np.array_equal(reinhard, oracle.OracleRenderer(flat).present(a8, wl, ws))
     assert not np.array_equal(reinhard, ward)
+
+
+def test_buffers_too_small_for_the_first_frame_are_grown_and_the_frame_repeated():
+    """rt_trace sizes the ray-tree levels and the leaf-record buffers from earlier frames; a frame that does not fit
+    is traced again with larger buffers (rt_trace_end returns 1). Started far too small, the result must still be
+    exact, and the following frame must fit without a repeat."""
+    flat = make_flat("bun_zipper_res4.ply", 331, 203, depth=4, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    want = render_hip(flat)
+    rt = abi.RayTracerHIP(flat.cfg)
+    rt.setScene(flat)
+    rt.setOption("first_level_rays", 256)
+    rt.setOption("first_records", 512)
+    rt.traceBegin()
+    assert rt.traceEnd() is True
+    assert np.array_equal(rt.readRGBA8(), want.readRGBA8())
+    assert np.array_equal(rt.readFloat(), want.readFloat(), equal_nan=True)
+    assert np.array_equal(rt.readHitIds(), want.readHitIds())
+    assert rt.stats().rays_total == want.stats().rays_total and rt.stats().shadow_rays == want.stats().shadow_rays
+    rt.traceBegin()
+    assert rt.traceEnd() is False
+    assert np.array_equal(rt.readRGBA8(), want.readRGBA8())
