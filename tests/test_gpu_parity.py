@@ -340,3 +340,36 @@ def test_buffers_too_small_for_the_first_frame_are_grown_and_the_frame_repeated(
     rt.traceBegin()
     assert rt.traceEnd() is False
     assert np.array_equal(rt.readRGBA8(), want.readRGBA8())
+
+
+def test_pipelined_job_repeats_the_exchange_of_a_retraced_frame():
+    """Contexts that start with buffers far too small: rt_trace_end reports the repeat one frame later, and the job
+    queues the tone reduction and the present pass of that frame again. The frames must come out exact."""
+    import ctypes as C
+    import torch
+    from ray_tracer_amd import multi_gpu
+    flat = make_flat("bun_zipper_res4.ply", 203, 117, depth=3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    ref = render_hip(flat)
+    wl, ws = ref.tone()
+    want_canvas = ref.present()
+    rts = []
+    for _ in range(2):
+        rt = abi.RayTracerHIP(flat.cfg)
+        rt.setScene(flat)
+        rt.setOption("first_level_rays", 256)
+        rt.setOption("first_records", 512)
+        rts.append(rt)
+    job = multi_gpu.PipelinedFrameJob(rts, multi_gpu.Comm(0, 1, 0, backend=None, device="cuda:0"))
+    job.step()
+    job.step()
+    job.flush()
+    torch.cuda.synchronize()
+    assert job.redone == 2
+    for rt in rts:
+        assert np.array_equal(rt.readRGBA8(), ref.readRGBA8())
+        gl, gs = rt.toneGet()
+        assert abs(gl - wl) <= 1e-12 * wl and np.float32(gs) == np.float32(ws)
+        p, n = C.c_void_p(), C.c_size_t()
+        assert rt.L.rt_device_canvas(rt.ctx, C.byref(p), C.byref(n)) == 0
+        canvas = torch.as_tensor(multi_gpu._DevView(p.value, n.value), device="cuda:0").cpu().numpy()
+        assert np.array_equal(canvas.reshape(want_canvas.shape), want_canvas)
