@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--emulate-shards", type=int, default=0, help="single rank only: trace shard 0 of N (what one GPU of an N-GPU job does, without the exchange)")
     ap.add_argument("--parts", type=int, default=0, help="concurrent slices per GPU (0 = library default)")
     ap.add_argument("--in-flight", type=int, default=3, help="frames in flight per GPU (contexts that alternate frames); 1 = finish every frame before the next")
-    ap.add_argument("--walk-waves", type=int, default=0, help="persistent walk waves per CU and context (0 = 24)")
+    ap.add_argument("--walk-waves", type=int, default=0, help="persistent walk waves per CU and context (0 = 24, 20 when tiles are exchanged between GPUs)")
     ap.add_argument("--sync-job", action="store_true", help="the host-synchronised frame job (every stage of the exchange waits on the host)")
     ap.add_argument("--kd-builder", default="host", choices=["host", "device"], help="where the k-d tree is built (same tree; the node blocks are laid out in a different order)")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "frames"],
@@ -95,7 +95,9 @@ def main():
     for _ in range(n_ctx):
         r = abi.RayTracerHIP(cfg)
         r.setScene(flat, kd_on_device=(args.kd_builder == "device"))
-        waves = args.walk_waves or 24
+        # with an exchange in flight, the persistent walk leaves a fifth of a CU's wave slots and LDS to the RCCL
+        # kernels of the other frames (at partial load the walk does not notice: profiles/r01n_frames_in_flight_sweep.txt)
+        waves = args.walk_waves or (20 if (world > 1 and not by_frames) else 24)
         r.setOption("walk_waves_per_cu", waves)
         r.setOption("stage_timing", 0)     # per-kernel events only on the detail frames after the timed region
         rts.append(r)
