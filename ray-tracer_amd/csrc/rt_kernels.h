@@ -433,6 +433,12 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
 #endif
         const bool at_leaf = (int32_t)info < 0;
         const bool is_int = info != 0u && !at_leaf;
+        // a lane at a leaf goes on with the newest entry of its stack. The entry is fetched first: the LDS read then
+        // runs under the arithmetic of the lanes at internal nodes instead of in front of the node fetch
+        const bool cont = at_leaf && tmax < maxDist;   // false on the last cell and on a NaN interval
+        const bool pop = cont && sp_top != sp_lo;
+        uint2 e = make_uint2(0u, __float_as_uint(maxDist));   // ring ran dry: restart at the root up to maxDist
+        if (pop) e = stack[((uint32_t)(sp_top - 1) & (SHORT_STACK - 1)) * WAVE];
         // internal node: classify the children and pick the side(s) the ray interval touches
         const uint32_t a = (info >> 28) & 3u;
         const float o = a == 0u ? ox : (a == 1u ? oy : oz), d = a == 0u ? dx : (a == 1u ? dy : dz);
@@ -459,10 +465,6 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
         const bool is_listed = info >= 0xc0000000u LEAF_EMIT_COND;
         const unsigned long long listed = __builtin_amdgcn_ballot_w64(is_listed);
         const uint32_t leaf_info = info & 0x3fffffffu;
-        const bool cont = at_leaf && tmax < maxDist;   // false on the last cell and on a NaN interval
-        const bool pop = cont && sp_top != sp_lo;
-        uint2 e = make_uint2(0u, __float_as_uint(maxDist));   // ring ran dry: restart at the root up to maxDist
-        if (pop) e = stack[((uint32_t)(sp_top - 1) & (SHORT_STACK - 1)) * WAVE];
         sp_top += both ? 1 : (pop ? -1 : 0);                  // a push and a pop never meet in one action
         sp_lo = max(sp_lo, sp_top - SHORT_STACK);             // a push onto a full ring drops the oldest entry
         tmin = cont ? tmax : tmin;
