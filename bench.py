@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--cpu-step", type=int, default=1, help="CPU baseline traces every n-th pixel in x and y")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--emulate-shards", type=int, default=0, help="single rank only: trace shard 0 of N (what one GPU of an N-GPU job does, without the exchange)")
+    ap.add_argument("--emulate-index", type=int, default=0, help="with --emulate-shards: which shard to trace")
     ap.add_argument("--parts", type=int, default=0, help="concurrent slices per GPU (0 = library default)")
     ap.add_argument("--in-flight", type=int, default=3, help="frames in flight per GPU (contexts that alternate frames); 1 = finish every frame before the next")
     ap.add_argument("--walk-waves", type=int, default=0, help="persistent walk waves per CU and context (0 = 24, 20 when tiles are exchanged between GPUs)")
@@ -85,7 +86,7 @@ def main():
     by_frames = args.shard == "frames" and world > 1
     job_comm = multi_gpu.Comm(0, 1, local, backend=None, device="cuda:%d" % local) if by_frames else comm
     shard_count = args.emulate_shards if (world == 1 and args.emulate_shards > 1) else (1 if by_frames else world)
-    cfg = abi.default_config(args.width, args.height, depth=args.depth, shard_index=0 if by_frames else rank, shard_count=shard_count,
+    cfg = abi.default_config(args.width, args.height, depth=args.depth, shard_index=0 if by_frames else (args.emulate_index if (world == 1 and args.emulate_shards > 1) else rank), shard_count=shard_count,
                              device=local, parts=args.parts)
     flat = abi.FlatScene(sc, cfg, scene.camera_rays(args.width, args.height))
     pipelined = not args.sync_job and (world == 1 or by_frames or args.backend == "nccl")
