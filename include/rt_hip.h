@@ -183,6 +183,10 @@ int rt_read_rgba8(rt_ctx *ctx, uint8_t *rgba);
 /* primary hit ids, one int32 per pixel: -1 miss, 0..n_prims-1 analytic primitive,
  * n_prims + face index for a mesh triangle */
 int rt_read_hit_ids(rt_ctx *ctx, int32_t *ids);
+/* the primary hit id of one pixel of the last traced frame (x, y in render-target pixels, y = 0 the bottom row): what
+ * the reference's mouse picking finds by intersecting the pixel's primary ray with every object on the CPU
+ * (UI.onMouseDown -> getPrimaryRay + Primitive.intersect, js/8-kd_tree.js:2718-2760) */
+int rt_pick(rt_ctx *ctx, int32_t x, int32_t y, int32_t *id);
 
 /* ---- tone reproduction: replaces the CPU loop of js/8-kd_tree.js:2559-2569 --------------- */
 /* partial sums over this shard: sum of log(EPSILON + L) and pixel count; the multi-GPU

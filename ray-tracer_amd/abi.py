@@ -146,6 +146,7 @@ def lib():
         L.rt_read_float.argtypes = [vp, vp]
         L.rt_read_rgba8.argtypes = [vp, vp]
         L.rt_read_hit_ids.argtypes = [vp, vp]
+        L.rt_pick.argtypes = [vp, i32, i32, C.POINTER(C.c_int32)]
         L.rt_tone_partial.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.rt_tone_finish.argtypes = [vp, C.c_double, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rt_tone.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -273,6 +274,12 @@ class RayTracerHIP:
         out = np.full((self.H, self.W), -2, np.int32)
         self._ck(self.L.rt_read_hit_ids(self.ctx, out.ctypes.data), "rt_read_hit_ids")
         return out
+
+    def pick(self, x, y):
+        """Primary hit id of pixel (x, y), y = 0 at the bottom: -1 miss, analytic primitive index, or n_prims + face."""
+        v = C.c_int32()
+        self._ck(self.L.rt_pick(self.ctx, x, y, C.byref(v)), "rt_pick")
+        return v.value
 
     def tonePartial(self):
         s, n = C.c_double(), C.c_uint64()

@@ -956,6 +956,18 @@ static int queue_tone_reduction(rt_ctx *ctx) {
     return 0;
 }
 
+int rt_pick(rt_ctx *ctx, int32_t x, int32_t y, int32_t *id) {
+    if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_pick: host-only context (created with device = -1)");
+    if (!id) return fail(ctx, "rt_pick: null argument");
+    if (!ctx->traced) return fail(ctx, "rt_pick: nothing traced yet");
+    if (ctx->in_flight) return fail(ctx, "rt_pick: a frame is in flight, call rt_trace_end first");
+    if (x < 0 || y < 0 || x >= ctx->g.W || y >= ctx->g.H) return fail(ctx, "rt_pick: pixel outside the render target");
+    HIPCK(hipSetDevice(ctx->cfg.device));
+    HIPCK(hipMemcpy(id, ctx->d_hit + (size_t)y * ctx->g.W + x, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int rt_tone_partial(rt_ctx *ctx, double *sum_log, uint64_t *count) {
     if (!ctx) return -1;
     if (ctx->host_only) return fail(ctx, "rt_tone_partial: host-only context (created with device = -1)");

@@ -292,6 +292,18 @@ READ_INTO(js_read_float, rt_read_float, float)
 READ_INTO(js_read_rgba8, rt_read_rgba8, uint8_t)
 READ_INTO(js_read_hit_ids, rt_read_hit_ids, int32_t)
 
+static napi_value js_pick(napi_env env, napi_callback_info info) {
+    ARGS(3)
+    rt_ctx *ctx; int32_t x, y, id = -1;
+    if (!get_ctx(env, argv[0], &ctx)) return NULL;
+    NAPI_OK(napi_get_value_int32(env, argv[1], &x));
+    NAPI_OK(napi_get_value_int32(env, argv[2], &y));
+    if (rt_pick(ctx, x, y, &id) != 0) return throw_rt(env, ctx, "rt_pick");
+    napi_value v;
+    NAPI_OK(napi_create_int32(env, id, &v));
+    return v;
+}
+
 static napi_value js_tone(napi_env env, napi_callback_info info) {
     ARGS(1)
     rt_ctx *ctx;
@@ -353,7 +365,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"buildKdTree", js_build_kdtree}, {"buildKdTreeDevice", js_build_kdtree_device}, {"kdtreeCounts", js_kdtree_counts},
         {"exportKdTree", js_export_kdtree}, {"kdRootBox", js_kd_root_box},
         {"trace", js_trace}, {"traceBegin", js_trace_begin}, {"traceEnd", js_trace_end}, {"readFloat", js_read_float}, {"readRGBA8", js_read_rgba8}, {"readHitIds", js_read_hit_ids},
-        {"tone", js_tone}, {"present", js_present}, {"stats", js_stats},
+        {"pick", js_pick}, {"tone", js_tone}, {"present", js_present}, {"stats", js_stats},
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; i++) {
         napi_value fn;

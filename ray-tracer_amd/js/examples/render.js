@@ -43,6 +43,8 @@ const sha = (u8) => crypto.createHash('sha256').update(Buffer.from(u8.buffer, u8
     const out = { width: G.WIDTH, height: G.HEIGHT, depth: G.MAX_RECURSION_DEPTH, model: G.MODEL_FILE_NAME, frames,
         Lbar: tracer.Lbar, sf: tracer.sf, rgba8_sha256: sha(tracer.pixels), canvas_sha256: sha(canvas),
         rays: st.raysTotal, shadow_rays: st.shadowRays, trace_ms: st.traceMs, kd_build_ms: st.kdBuildMs, wall_ms_per_frame: ms };
+    const pk = arg('pick', null);   // --pick x,y (canvas pixel, y from the top): class name of the object under it
+    if (pk) { const o = tracer.pick(...pk.split(',').map(Number)); out.picked = o ? o.constructor.name : null; }
     const ppm = arg('ppm', null);
     if (ppm) {   // canvas rows are bottom-up; PPM is top-down
         const W = G.WIDTH, H = G.HEIGHT, body = Buffer.alloc(W * H * 3);

@@ -211,6 +211,18 @@ function makeRayTracer(G, THREE, api) {
             addon.readHitIds(this.ctx, out, out.byteLength);
             return out;
         }
+        // What the reference's mouse picking computes on the CPU (js/8-kd_tree.js:2718-2760): the object under canvas
+        // pixel (x, y), y counted from the top as mouse events do. Returns the scene object (the Mesh for any of its
+        // faces) or null.
+        pick(x, y) {
+            const S = G.SUPERSAMPLING;
+            const id = addon.pick(this.ctx, Math.floor(x * S), Math.floor((this.height - 1 - y) * S + (S - 1)));
+            if (id < 0) return null;
+            const prims = this.scene.objects.filter((o) => !(o instanceof api.Mesh));
+            if (id < prims.length) return prims[id];
+            const f = id - prims.length;   // index into g_faces: every Mesh owns a contiguous range of it
+            return this.scene.objects.find((o) => o instanceof api.Mesh && f >= o.startFaceIndex && f < o.startFaceIndex + o.facesLength) || null;
+        }
         exportKdBox() { const box = new Float64Array(6); addon.kdRootBox(this.ctx, box); return box; }
         exportKdTree() {
             const [nn, nl] = addon.kdtreeCounts(this.ctx);

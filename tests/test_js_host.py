@@ -91,6 +91,13 @@ def test_js_render_equals_python_binding():
     assert out["rays"] == rt.stats().rays_total
     for k in ("rgba8_sha256", "canvas_sha256", "Lbar", "sf", "rays"):
         assert out_dev[k] == out[k], k
+    # picking (the reference intersects the pixel's primary ray on the CPU): centre of the canvas = the glass sphere,
+    # a corner of the sky = nothing, a pixel of the bunny = the mesh; and rt_pick agrees with the hit-id buffer
+    for xy, want in (("320,240", "Sphere"), ("2,2", None), ("330,40", "Mesh")):
+        assert run_node(args + ["--pick", xy])["picked"] == want, xy
+    ids = rt.readHitIds()
+    for x, y in ((320, 239), (2, 477), (330, 439), (100, 50)):
+        assert rt.pick(x, y) == ids[y, x]
     rt.close()
 
 
