@@ -7,15 +7,15 @@
 //
 //   k_gen_prims    one lane per ray: (level 0: generate the primary ray) closest hit over the analytic
 //                  primitives; rays whose interval overlaps the k-d root box go to the walk queue
-//   k_kd_walk<0>   persistent waves walk the tree for the queued rays and only LIST the triangles of the
-//                  leaves they cross, as (ray, triangle slot) records in visit order
-//   k_tri_test<0>  one lane per record: Moller-Trumbore, 64-bit atomic min of (t, record index) per ray
-//   k_shade_a      one lane per ray: resolves the mesh hit, miss -> background, hit -> one shadow ray per
-//                  light: analytic any-hit test here, survivors that reach the k-d box go to the shadow queue
-//   k_kd_walk<1>   the same walk for the shadow queue
-//   k_tri_test<1>  one lane per record: any hit sets the light's shadow bit of the ray
-//   k_shade_b      one lane per ray: Phong terms with the shadow bits, spawns the children into the next
-//                  level's queue
+//   k_kd_walk      persistent waves walk the tree for the queued rays and only LIST the leaves they cross, as
+//                  (ray, leaf's triangle slots) records; one launch serves the closest-hit rays of a level and
+//                  the shadow rays of the level before it
+//   k_tri_test     one lane per record: Moller-Trumbore; closest hit: 64-bit atomic min per ray of (t, visit rank
+//                  of the leaf, face position); shadow: any hit sets the light's shadow bit of the ray
+//   k_shade_a      one lane per ray: resolves the mesh hit, miss -> background, hit -> the two children into the
+//                  next level's queue and one shadow ray per light: analytic any-hit test here, survivors that
+//                  reach the k-d box go to the shadow queue
+//   k_shade_b      one lane per ray, one step later: Phong terms with the finished shadow bits
 //
 // Walking and testing can be separated because the reference's closest-hit search never stops early: it
 // crosses every cell of the root interval and keeps the minimum t (js/8-kd_tree.js:862-962), so which
@@ -40,7 +40,7 @@ struct LevelBuf {
     uint32_t *hp;                        // analytic winner | last analytic hit << 16 (0xffff = none)
     int32_t *hf;                         // winning mesh face or -1
     uint32_t *shadow;                    // bit i: light i is occluded
-    unsigned long long *best;            // closest mesh hit: t bits << 32 | record index, ~0 = none
+    unsigned long long *best;            // closest mesh hit: t bits << 32 | visit rank of the leaf << 2 | face position, ~0 = none
     float *cr, *cg, *cb;                 // local colour, later the folded colour
     float *kr, *kt;                      // kReflect / kRefract of this node
     int32_t *refl, *refr;                // queue slot of the child in the next level, -1 = none
@@ -477,8 +477,8 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
             split = n.split;
         }
 
-        // ---- list the leaves just visited: one record (ray, leaf's slot range) per non-empty leaf; records of
-        //      one ray only ever move forward in the buffer, so the buffer order is the visit order
+        // ---- list the leaves just visited: one record (ray, leaf's slot range) per non-empty leaf, in no
+        //      particular order (k_tri_test needs none)
         if (listed) {
             const uint32_t tot = COUNT_OF(listed);
             if (rec_end - rec_pos < tot) {
