@@ -32,11 +32,15 @@ HBM_PEAK_GBS = 8000.0
 FP32_PEAK_TFLOPS = 157.3
 
 
-def build_workload(args):
-    teapot = (os.path.join(ROOT, "assets", "models", "teapot.obj"), 60.0, (50.0, 75.0, 10.0)) if args.teapot else None
-    sc = scene.default_scene(os.path.join(ROOT, "assets", "models", args.model), mesh_material=MESH_MATERIAL,
-                             extra_mesh=teapot)
-    scene.animate_light(sc, args.time)
+TEAPOT = (os.path.join(ROOT, "assets", "models", "teapot.obj"), 60.0, (50.0, 75.0, 10.0))   # file, scale, translation (checkpoint 6 places it so, js/6-transmission.js:2010-2014)
+
+
+def build_workload(model="bun_zipper.ply", teapot=True, time=0.0):
+    """BASELINE config 3: the default 8-kd_tree.js scene, full bunny + teapot.obj as a second mesh (indices rebased), the
+    mesh material reflective and transmissive. tests/test_gpu_parity.py renders exactly this scene against the oracle."""
+    sc = scene.default_scene(os.path.join(ROOT, "assets", "models", model), mesh_material=MESH_MATERIAL,
+                             extra_mesh=TEAPOT if teapot else None)
+    scene.animate_light(sc, time)
     return sc
 
 
@@ -82,7 +86,7 @@ def main():
     comm = (multi_gpu.Comm(rank, world, local, backend=args.backend, device="cuda:%d" % local) if world > 1
             else multi_gpu.Comm(0, 1, local, backend=None, device="cuda:%d" % local))
 
-    sc = build_workload(args)
+    sc = build_workload(args.model, bool(args.teapot), args.time)
     by_frames = args.shard == "frames" and world > 1
     job_comm = multi_gpu.Comm(0, 1, local, backend=None, device="cuda:%d" % local) if by_frames else comm
     shard_count = args.emulate_shards if (world == 1 and args.emulate_shards > 1) else (1 if by_frames else world)

@@ -130,7 +130,9 @@ const char *rt_last_error(const rt_ctx *ctx);
 void rt_default_config(rt_config *cfg);
 
 /* ---- scene: replaces the uniform marshalling of RayTracer.update (js/8-kd_tree.js:2435-2453,
- *      :1104-1126) and the shader regeneration of RayTracer.setScene (:2347-2431) -------- */
+ *      :1104-1126) and the shader regeneration of RayTracer.setScene (:2347-2431) --------
+ * Every call that changes the scene, the mesh, the tree or the walk's launch shape fails between rt_trace_begin and
+ * rt_trace_end: the queued frame still reads them. */
 int rt_set_primitives(rt_ctx *ctx, const rt_prim *prims, int32_t n);
 int rt_set_materials(rt_ctx *ctx, const rt_material *mats, int32_t n);
 /* n_loop is the trip count of the light loop baked into the shader (`nextPointLightId`,
@@ -181,7 +183,8 @@ int rt_read_float(rt_ctx *ctx, float *rgb);
 /* = gl.readPixels(RGBA, UNSIGNED_BYTE) of the render target (js/8-kd_tree.js:2558) */
 int rt_read_rgba8(rt_ctx *ctx, uint8_t *rgba);
 /* primary hit ids, one int32 per pixel: -1 miss, 0..n_prims-1 analytic primitive,
- * n_prims + face index for a mesh triangle */
+ * n_prims + face index for a mesh triangle. Hit ids are not gathered between shards: on a sharded context the pixels
+ * of the other shards read -1, and rt_pick on such a pixel fails. */
 int rt_read_hit_ids(rt_ctx *ctx, int32_t *ids);
 /* the primary hit id of one pixel of the last traced frame (x, y in render-target pixels, y = 0 the bottom row): what
  * the reference's mouse picking finds by intersecting the pixel's primary ray with every object on the CPU
@@ -234,7 +237,9 @@ int rt_stream(rt_ctx *ctx, void **stream);
  * around every stage kernel, which fill rt_stats.level_stage_ms / stage_ms / level_kernel_ms; without them those
  * fields are zero and a frame is about forty queue entries shorter. "first_level_rays" / "first_records" (0 = default):
  * capacity of the deeper ray-tree levels / of the leaf-record buffers on a context's first frame; later frames use what
- * the earlier ones needed (a frame that does not fit is traced again, see rt_trace_end). No counterpart in the reference. */
+ * the earlier ones needed (a frame that does not fit is traced again, see rt_trace_end). "poison_records" (0 / 1, test
+ * hook): leaf-record buffers are filled with 0xff bytes when they are allocated, so that a kernel reading a record no
+ * walk wrote shows up as a fault or a wrong image instead of going unnoticed. No counterpart in the reference. */
 int rt_set_option(rt_ctx *ctx, const char *name, double value);
 
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);

@@ -19,3 +19,12 @@ node $H --script 7-tone_reproduction.js --pixels zero --out $G/tone7_zero_640x48
 node $H --script 7-tone_reproduction.js --pixels const:10,200,30 --set TONE_REPRODUCTION_METHOD=1 --out $G/tone7_const_640x480
 # BASELINE config 1: checkpoint 6
 node $H --script 6-transmission.js --ticks 2 --out $G/c1_ch6_640x480
+# BASELINE config 3 as benchmarked: full bunny + teapot.obj (the reference's own loadOBJ and Mesh class; the harness
+# rebases the second mesh's indices), reflective + transmissive mesh material, depth 5, 3840x2160
+node $H --script $K8 --model models/bun_zipper.ply --width 3840 --height 2160 --depth 5 \
+     --mesh-material 0.7,0.6,0.7,16,0.3,0.5,0.9 --extra-obj models/teapot.obj --extra-scale 60 --extra-translate 50,75,10 \
+     --out $G/c3_bunny_teapot
+# the same two meshes at the smallest bunny resolution, full arrays kept (teapot ingest can be diffed element by element)
+node $H --script $K8 --model models/bun_zipper_res4.ply --depth 3 \
+     --mesh-material 0.7,0.6,0.7,16,0.3,0.5,0.9 --extra-obj models/teapot.obj --extra-scale 60 --extra-translate 50,75,10 \
+     --out $G/k8_res4_teapot_640x480 --full-arrays

@@ -14,6 +14,17 @@
  *        --width 640 --height 480 --depth 1 --ss 1 --time 0 --out DIR [--full-arrays]
  *        [--set NAME=VALUE ...]   (edits `const NAME = ...;` lines, which is how the
  *                                  reference is configured: js/8-kd_tree.js:25-46)
+ *        [--mesh-material ka,kd,ks,ke,kReflect,kRefract,ior]   (edits the constants of the mesh's Phong
+ *                                  material inside generateScene, js/8-kd_tree.js:2963)
+ *        [--extra-obj models/teapot.obj --extra-scale 60 --extra-translate 50,75,10]
+ *              a second mesh: loaded by the reference's own loadOBJ (js/8-kd_tree.js:2851-2887), constructed,
+ *              scaled and translated with the reference's own Mesh class and given the first mesh's material.
+ *              Mesh.pushToGlobal appends faces without rebasing their vertex indices (js/8-kd_tree.js:2114-2115;
+ *              the reference only ever loads one mesh), so THIS HARNESS adds the mesh's first vertex index to
+ *              its faces afterwards - the one step that is not the reference's own code.
+ *        [--drag x0,y0,x1,y1]  drives ui.mouseDown(x0,y0), ui.mouseMove(x1,y1), ui.mouseUp(x1,y1)
+ *              (js/8-kd_tree.js:2718-2792) after the first tick and records what was picked and how the
+ *              picked object's transform changed; a further tick then renders the moved scene
  */
 'use strict';
 const fs = require('fs');
@@ -25,7 +36,8 @@ const REF = process.env.RT_REFERENCE || '/root/reference';
 
 function parseArgs(argv) {
     const a = { script: '8-kd_tree.js', width: 640, height: 480, time: 0, sets: {}, fullArrays: false,
-                pixelPattern: 'lcg', out: null, ticks: 1 };
+                pixelPattern: 'lcg', out: null, ticks: 1,
+                meshMaterial: null, extraObj: null, extraScale: 1, extraTranslate: [0, 0, 0], drag: null };
     for (let i = 2; i < argv.length; i++) {
         const k = argv[i];
         if (k === '--script') a.script = argv[++i];
@@ -39,6 +51,11 @@ function parseArgs(argv) {
         else if (k === '--full-arrays') a.fullArrays = true;
         else if (k === '--ticks') a.ticks = +argv[++i];
         else if (k === '--pixels') a.pixelPattern = argv[++i];
+        else if (k === '--mesh-material') a.meshMaterial = argv[++i].split(',').map(Number);
+        else if (k === '--extra-obj') a.extraObj = argv[++i];
+        else if (k === '--extra-scale') a.extraScale = +argv[++i];
+        else if (k === '--extra-translate') a.extraTranslate = argv[++i].split(',').map(Number);
+        else if (k === '--drag') a.drag = argv[++i].split(',').map(Number);
         else if (k === '--set') { const [n, v] = argv[++i].split('='); a.sets[n] = v; }
         else throw new Error('unknown arg ' + k);
     }
@@ -156,6 +173,32 @@ runRef('js/' + args.script, (src) => {
         if (!re.test(src)) throw new Error('constant not found: ' + name);
         src = src.replace(re, (m, kw) => { usedSets[name] = args.sets[name]; return kw + ' ' + name + ' = ' + args.sets[name] + ';'; });
     }
+    if (args.meshMaterial) {
+        const re = /(var meshMaterial = new Phong\(nextPhongId\+\+,)[^\n]*\n/;
+        if (!re.test(src)) throw new Error('mesh material line not found');
+        src = src.replace(re, (m, head) => head + ' ' + args.meshMaterial.join(', ') + ',\n');
+        usedSets.meshMaterial = args.meshMaterial.join(',');
+    }
+    if (args.extraObj) {
+        // the second mesh is loaded next to the first and added between generateScene() and ui.setScene()
+        const a = 'loadPLY(MODEL_FILE_NAME).then(function(data) {';
+        const b = 'var scene = generateScene(meshes);';
+        if (src.indexOf(a) < 0 || src.indexOf(b) < 0) throw new Error('initWebGL hooks not found');
+        src = src.replace(a, 'Promise.all([loadPLY(MODEL_FILE_NAME), loadOBJ(' + JSON.stringify(args.extraObj) +
+                             ')]).then(function(all) { var data = all[0]; var __extra = all[1];');
+        src = src.replace(b, b + `
+            (function () {
+                var m2 = new Mesh(nextObjectId++, __extra.verts, __extra.faces);
+                m2.scale(new THREE.Vector3(${args.extraScale}, ${args.extraScale}, ${args.extraScale}));
+                m2.translate(new THREE.Vector3(${args.extraTranslate.join(', ')}));
+                m2.setMaterial(scene.objects[scene.objects.length - 1].faces[0].getMaterial());
+                for (var t = 0; t < m2.faces.length; t++)      // the harness's rebase (not reference code)
+                    for (var j = 0; j < 3; j++) m2.faces[t].indices[j] += m2.startVertIndex;
+                scene.objects.push(m2);
+            })();`);
+        usedSets.extra_mesh = args.extraObj + ' scale ' + args.extraScale + ' translate ' + args.extraTranslate.join(',') +
+                              ' (indices rebased by the harness)';
+    }
     return src;
 });
 
@@ -168,6 +211,40 @@ setImmediate(() => {
     // checkpoint 6 sets its uniforms AFTER the draw (js/6-transmission.js:1619-1624): a second tick is
     // the first frame that renders with them. Uniform values are identical in both ticks.
     if (args.ticks > 1) for (let k = 1; k < args.ticks; k++) vm.runInContext('tick(' + args.time + ')', sandbox);
+    let dragRecord = null;
+    if (args.drag) {
+        // a click selects, a second press on the selection box grabs, moves follow, release ends (UI.mouseDown /
+        // mouseMove / mouseUp, js/8-kd_tree.js:2718-2792, driven like the handlers at :3054-3088 do)
+        const d = args.drag;
+        sandbox.__drag = d;
+        dragRecord = vm.runInContext(`(function () {
+            var d = __drag, rec = {};
+            rec.select_returned = ui.mouseDown(d[0], d[1]);
+            ui.mouseUp(d[0], d[1]);
+            var sel = ui.renderer.selectedObject;
+            rec.selected_index = ui.scene.objects.indexOf(sel);
+            if (sel) {
+                rec.model_before = Array.from(sel.modelTransform.elements);
+                rec.grab_returned = ui.mouseDown(d[0], d[1]);
+                rec.moving = ui.moving;
+                rec.zPos = ui.zPos;
+                rec.old_position = [ui.oldPosition.x, ui.oldPosition.y, ui.oldPosition.z];
+                rec.positions = [];
+                for (var k = 2; k + 1 < d.length; k += 2) {
+                    ui.mouseMove(d[k], d[k + 1]);
+                    rec.positions.push([ui.oldPosition.x, ui.oldPosition.y, ui.oldPosition.z]);
+                }
+                ui.mouseUp(d[d.length - 2], d[d.length - 1]);
+                rec.positions.push([ui.oldPosition.x, ui.oldPosition.y, ui.oldPosition.z]);
+                rec.model_after = Array.from(sel.modelTransform.elements);
+                rec.inv_model_after = Array.from(sel.invModelTransform.elements);
+            }
+            return rec;
+        })()`, sandbox);
+        dragRecord.mouse = d;
+        // the frame after the drag; time advanced past the rebuild throttle (js/8-kd_tree.js:2495) so the tree follows
+        vm.runInContext('tick(' + (args.time + 0.5) + ')', sandbox);
+    }
 
     fs.mkdirSync(args.out, { recursive: true });
     const sha = (buf) => crypto.createHash('sha256').update(Buffer.from(buf.buffer, buf.byteOffset, buf.byteLength)).digest('hex');
@@ -237,6 +314,7 @@ setImmediate(() => {
         },
         Lbar: rt ? rt.Lbar : null, sf: rt ? rt.sf : null,
         first_vert_f64: nV ? [v64[0], v64[1], v64[2]] : null,
+        drag: dragRecord,
     };
 
     if (rt && rt.kdTree) {

@@ -38,6 +38,13 @@ struct Level {
 
 constexpr int MAX_PARTS = 8;
 
+// A walking wave reserves leaf records in chunks of REC_CHUNK and writes nothing into a chunk that would cross the end
+// of the buffer, so only whole chunks are ever written: this is the capacity the walk, the triangle tests and the
+// overflow check all use (a tail shorter than a chunk would be read by the tests without ever being written).
+inline uint32_t usable_records(size_t cap) {
+    return (uint32_t)(std::min<size_t>(cap, 0x3fffff00u) / (size_t)REC_CHUNK * (size_t)REC_CHUNK);
+}
+
 // One independent slice of the shard's tiles. Every part has its own stream, ray-tree levels, queues, record
 // buffer and counters, so the parts of a frame run concurrently: while the last long rays of one part's walk
 // drain (a persistent kernel ends only when its slowest ray does), the other parts' kernels fill the machine.
@@ -74,6 +81,7 @@ struct rt_ctx {
     int n_cus = 256;
     int walk_waves_per_cu = RT_WALK_WAVES_PER_CU;
     uint32_t first_level_rays = 0, first_records = 0;   // sizes of the first frame's buffers (0 = defaults), rt_set_option
+    bool poison_records = false;                 // test hook: new leaf-record buffers are filled with 0xff instead of left as allocated
     bool stage_timing = true;                    // events around every stage kernel (rt_stats.level_stage_ms)
     bool stage_timed = false;                    // the frame in flight was queued with them
     int n_parts = 1;
@@ -172,8 +180,12 @@ int ensure_level(rt_ctx *ctx, Part &P, int l, uint32_t cap) {
     return 0;
 }
 
+// a shadow-queue entry names its ray as (ray index << 5 | light): 27 bits of ray index
+constexpr uint32_t MAX_LEVEL_RAYS = 1u << 27;
+
 // traversal queues are shared by all levels: sized for the largest level seen so far
 int ensure_queues(rt_ctx *ctx, Part &P, int level, uint32_t n_rays, uint32_t n_lights) {
+    if (n_rays > MAX_LEVEL_RAYS) return fail(ctx, "rt_trace: a ray-tree level of more than 2^27 rays per part (raise rt_config.parts or shard the frame)");
     if (ensure(ctx, P.d_kdq, P.cap_kdq, n_rays)) return -1;
     const int q = level & 1;
     uint64_t want = (uint64_t)n_rays * std::max<uint32_t>(n_lights, 1);
@@ -444,6 +456,11 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
         P.g.compact_add = p;
         const uint32_t part_tiles = my_tiles > (uint32_t)p ? (my_tiles - (uint32_t)p + (uint32_t)np - 1u) / (uint32_t)np : 0u;
         P.n0 = part_tiles * 64u;
+        if (P.n0 > MAX_LEVEL_RAYS) {
+            g_create_error = "rt_create: more than 2^27 rays per part at this size; raise rt_config.parts or shard the frame";
+            rt_destroy(ctx);
+            return -1;
+        }
     }
     ctx->stream = ctx->parts[0].stream;
     const size_t npx = (size_t)g.W * g.H;
@@ -454,6 +471,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     ALLOC(ctx->d_fb, npx * 3 * sizeof(float));
     ALLOC(ctx->d_rgba, npx * 4);
     ALLOC(ctx->d_hit, npx * 4);
+    if ((e = hipMemset(ctx->d_hit, 0xff, npx * 4)) != hipSuccess) return bail("hipMemset", e);   // -1: pixels of other shards are never written
     ALLOC(ctx->d_compact, std::max<size_t>(ctx->n0, 64) * 4);
     ALLOC(ctx->d_canvas, (size_t)cfg->width * cfg->height * 4);
     ALLOC(ctx->d_part_sum, TONE_BLOCKS * sizeof(double));
@@ -501,6 +519,7 @@ void rt_destroy(rt_ctx *ctx) {
 int rt_set_primitives(rt_ctx *ctx, const rt_prim *prims, int32_t n) {
     if (!ctx) return -1;
     if (n < 0 || (n > 0 && !prims)) return fail(ctx, "rt_set_primitives: bad arguments");
+    if (ctx->in_flight) return fail(ctx, "rt_set_primitives: a frame is in flight, call rt_trace_end first");
     if (n > 60000) return fail(ctx, "rt_set_primitives: at most 60000 primitives");
     for (int i = 0; i < n; i++)
         if (prims[i].kind < RT_PRIM_PLANE || prims[i].kind > RT_PRIM_CYLINDER) return fail(ctx, "rt_set_primitives: unknown primitive kind");
@@ -514,6 +533,7 @@ int rt_set_primitives(rt_ctx *ctx, const rt_prim *prims, int32_t n) {
 int rt_set_materials(rt_ctx *ctx, const rt_material *mats, int32_t n) {
     if (!ctx) return -1;
     if (n < 0 || (n > 0 && !mats)) return fail(ctx, "rt_set_materials: bad arguments");
+    if (ctx->in_flight) return fail(ctx, "rt_set_materials: a frame is in flight, call rt_trace_end first");
     for (int i = 0; i < n; i++)
         if (mats[i].type < RT_MAT_PHONG || mats[i].type > RT_MAT_PHONG_CHECKERED) return fail(ctx, "rt_set_materials: unknown material type");
     if ((size_t)n == ctx->mats_host.size() && (n == 0 || memcmp(mats, ctx->mats_host.data(), (size_t)n * sizeof(rt_material)) == 0)) return 0;
@@ -526,6 +546,7 @@ int rt_set_materials(rt_ctx *ctx, const rt_material *mats, int32_t n) {
 int rt_set_lights(rt_ctx *ctx, const rt_light *lights, int32_t n, int32_t n_loop) {
     if (!ctx) return -1;
     if (n < 0 || (n > 0 && !lights) || n_loop < n) return fail(ctx, "rt_set_lights: bad arguments (need n >= 0, n_loop >= n)");
+    if (ctx->in_flight) return fail(ctx, "rt_set_lights: a frame is in flight, call rt_trace_end first");
     if (n_loop > MAX_LIGHTS) return fail(ctx, "rt_set_lights: at most 32 lights");
     ctx->lights.assign((size_t)n_loop, LightDev{{0, 0, 0, 0}, {0, 0, 0, 0}});
     for (int i = 0; i < n; i++)
@@ -537,6 +558,7 @@ int rt_set_lights(rt_ctx *ctx, const rt_light *lights, int32_t n, int32_t n_loop
 int rt_set_globals(rt_ctx *ctx, const float ambient[3], const float bg[3]) {
     if (!ctx) return -1;
     if (!ambient || !bg) return fail(ctx, "rt_set_globals: null argument");
+    if (ctx->in_flight) return fail(ctx, "rt_set_globals: a frame is in flight, call rt_trace_end first");
     for (int k = 0; k < 3; k++) { ctx->sh.ambient[k] = ambient[k]; ctx->sh.bg[k] = bg[k]; }
     ctx->scene_dirty = true;
     return 0;
@@ -546,6 +568,7 @@ int rt_set_camera(rt_ctx *ctx, const float pos[3], const float r00[3], const flo
                   const float r11[3]) {
     if (!ctx) return -1;
     if (!pos || !r00 || !r01 || !r10 || !r11) return fail(ctx, "rt_set_camera: null argument");
+    if (ctx->in_flight) return fail(ctx, "rt_set_camera: a frame is in flight, call rt_trace_end first");
     for (int k = 0; k < 3; k++) {
         ctx->sh.cam[k] = pos[k]; ctx->sh.r00[k] = r00[k]; ctx->sh.r01[k] = r01[k]; ctx->sh.r10[k] = r10[k]; ctx->sh.r11[k] = r11[k];
     }
@@ -558,6 +581,7 @@ int rt_set_mesh(rt_ctx *ctx, const double *verts, int32_t n_verts, const uint32_
     if (!ctx) return -1;
     if (n_verts < 0 || n_faces < 0 || (n_verts > 0 && !verts) || (n_faces > 0 && (!faces || !face_mat)))
         return fail(ctx, "rt_set_mesh: bad arguments");
+    if (ctx->in_flight) return fail(ctx, "rt_set_mesh: a frame is in flight, call rt_trace_end first");
     for (int64_t i = 0; i < (int64_t)n_faces * 3; i++)
         if (faces[i] >= (uint32_t)n_verts) return fail(ctx, "rt_set_mesh: face index out of range");
     ctx->verts.assign(verts, verts + (size_t)n_verts * 3);
@@ -573,6 +597,7 @@ int rt_set_mesh(rt_ctx *ctx, const double *verts, int32_t n_verts, const uint32_
 int rt_build_kdtree_device(rt_ctx *ctx) {
     if (!ctx) return -1;
     if (ctx->host_only) return fail(ctx, "rt_build_kdtree_device: host-only context (created with device = -1)");
+    if (ctx->in_flight) return fail(ctx, "rt_build_kdtree_device: a frame is in flight, call rt_trace_end first");
     // a tree of one node (at most four faces, or no depth to split in) is not worth a launch
     if (ctx->faces.size() / 3 <= 4 || ctx->cfg.max_kd_depth <= 1) return rt_build_kdtree(ctx);
     HIPCK(hipSetDevice(ctx->cfg.device));
@@ -587,6 +612,7 @@ int rt_build_kdtree_device(rt_ctx *ctx) {
 
 int rt_build_kdtree(rt_ctx *ctx) {
     if (!ctx) return -1;
+    if (ctx->in_flight) return fail(ctx, "rt_build_kdtree: a frame is in flight, call rt_trace_end first");
     if (ctx->kd_on_device) { ctx->kd_on_device = false; ctx->mesh_dirty = true; }
     auto t0 = std::chrono::steady_clock::now();
     build_kdtree(ctx->verts.data(), (int64_t)ctx->verts.size() / 3, ctx->faces.data(), (int64_t)ctx->faces.size() / 3,
@@ -677,7 +703,7 @@ static int launch_step(rt_ctx *ctx, Part &P, int k) {
         J.best = P.lv[k].b.best;
         J.cnt = P.d_counts + k;
         J.recs = P.d_recs[0];
-        J.rec_cap = (uint32_t)std::min<size_t>(P.cap_recs[0], 0x3fffff00u);
+        J.rec_cap = usable_records(P.cap_recs[0]);
         J.enabled = walk ? 1u : 0u;
     }
     if (have_prev) {
@@ -688,7 +714,7 @@ static int launch_step(rt_ctx *ctx, Part &P, int k) {
         J.shadow = P.lv[k - 1].b.shadow;
         J.cnt = P.d_counts + (k - 1);
         J.recs = P.d_recs[1];
-        J.rec_cap = (uint32_t)std::min<size_t>(P.cap_recs[1], 0x3fffff00u);
+        J.rec_cap = usable_records(P.cap_recs[1]);
         J.q_cap = P.cap_shq[(k - 1) & 1];
         J.enabled = walk ? 1u : 0u;
     }
@@ -739,7 +765,11 @@ static int enqueue_part(rt_ctx *ctx, Part &P) {
     if (walk)
         for (int j = 0; j < 2; j++) {
             if (P.want_recs[j] == 0) P.want_recs[j] = ctx->first_records ? ctx->first_records : std::max<size_t>((size_t)8 << 20, (size_t)P.n0 * 8);
+            P.want_recs[j] = (P.want_recs[j] + (size_t)REC_CHUNK - 1) / (size_t)REC_CHUNK * (size_t)REC_CHUNK;
+            const uint2 *before = P.d_recs[j];
             if (ensure(ctx, P.d_recs[j], P.cap_recs[j], P.want_recs[j])) return -1;
+            if (ctx->poison_records && P.d_recs[j] != before)
+                HIPCK(hipMemsetAsync(P.d_recs[j], 0xff, P.cap_recs[j] * sizeof(uint2), s));
         }
     for (int k = 0; k <= D; k++)
         if (launch_step(ctx, P, k)) return -1;
@@ -779,12 +809,12 @@ static int finish_part(rt_ctx *ctx, Part &P) {
         const LevelCounters &hc = P.h_counts[l];
         if (l + 1 < D) {
             if (hc.next_count > P.lv[l + 1].cap) {
-                if (hc.next_count > 0x7fffff00u) return fail(ctx, "rt_trace: a ray-tree level exceeds 2^31 rays");
+                if (hc.next_count > MAX_LEVEL_RAYS) return fail(ctx, "rt_trace: a ray-tree level exceeds 2^27 rays per part (raise rt_config.parts or shard the frame)");
                 // the deeper levels usually grow by the same factor
                 const double f = (double)hc.next_count / (double)std::max<uint32_t>(P.lv[l + 1].cap, 1u);
                 for (int m = l + 1; m < D; m++) {
                     const double w = (m == l + 1 ? (double)hc.next_count : (double)P.lv[m].cap * f) * 1.25;
-                    P.want[m] = (uint32_t)std::min<double>(std::max<double>(w, (double)P.want[m]), (double)0x7fffff00u);
+                    P.want[m] = (uint32_t)std::min<double>(std::max<double>(w, (double)P.want[m]), (double)MAX_LEVEL_RAYS);
                 }
                 again = true;
             }
@@ -795,9 +825,9 @@ static int finish_part(rt_ctx *ctx, Part &P) {
         P.rec_total[1] += hc.rec_count[1];
     }
     for (int j = 0; j < 2 && walk; j++)
-        if (need_recs[j] > std::min<size_t>(P.cap_recs[j], 0x3fffff00u)) {
-            if (need_recs[j] > 0x3fffff00u) return fail(ctx, "rt_trace: leaf record buffer cannot hold one level");
-            P.want_recs[j] = need_recs[j] + need_recs[j] / 4;
+        if (need_recs[j] > usable_records(P.cap_recs[j])) {
+            if (need_recs[j] > usable_records(0x3fffff00u)) return fail(ctx, "rt_trace: leaf record buffer cannot hold one level");
+            P.want_recs[j] = std::min<size_t>(need_recs[j] + need_recs[j] / 4, 0x3fffff00u);
             again = true;
         }
     return again ? 1 : 0;
@@ -870,7 +900,11 @@ int rt_trace_begin(rt_ctx *ctx) {
     if (ctx->scene_dirty && upload_scene(ctx)) return -1;
     ctx->stage_timed = ctx->stage_timing;
     for (int p = 0; p < ctx->n_parts; p++)
-        if (enqueue_part(ctx, ctx->parts[p])) return -1;
+        if (enqueue_part(ctx, ctx->parts[p])) {
+            // part of the frame may be queued already: nothing of it may still run when the caller goes on
+            for (int q = 0; q < ctx->n_parts; q++) (void)hipStreamSynchronize(ctx->parts[q].stream);
+            return -1;
+        }
     // everything queued on the main stream after this call (tone, present, a caller's exchange) follows the trace
     for (int p = 1; p < ctx->n_parts; p++) HIPCK(hipStreamWaitEvent(ctx->stream, ctx->parts[p].ev_end, 0));
     ctx->in_flight = true;
@@ -963,6 +997,8 @@ int rt_pick(rt_ctx *ctx, int32_t x, int32_t y, int32_t *id) {
     if (!ctx->traced) return fail(ctx, "rt_pick: nothing traced yet");
     if (ctx->in_flight) return fail(ctx, "rt_pick: a frame is in flight, call rt_trace_end first");
     if (x < 0 || y < 0 || x >= ctx->g.W || y >= ctx->g.H) return fail(ctx, "rt_pick: pixel outside the render target");
+    if (((y / 8) * ctx->g.tiles_x + x / 8) % ctx->g.shard_count != ctx->g.shard_index)
+        return fail(ctx, "rt_pick: the pixel belongs to another shard (primary hit ids are not gathered)");
     HIPCK(hipSetDevice(ctx->cfg.device));
     HIPCK(hipMemcpy(id, ctx->d_hit + (size_t)y * ctx->g.W + x, sizeof(int32_t), hipMemcpyDeviceToHost));
     return 0;
@@ -1000,6 +1036,7 @@ int rt_tone_partial_device(rt_ctx *ctx, void **d_sum_count) {
 
 int rt_tone_finish(rt_ctx *ctx, double sum_log, uint64_t count, double *Lbar, double *sf) {
     if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_tone_finish: host-only context (created with device = -1)");
     if (count == 0) return fail(ctx, "rt_tone_finish: zero pixels");
     // Lbar = exp(sum / N); sf = ((1.219 + (Ldmax/2)^0.4) / (1.219 + Lbar^0.4))^2.5  (js/8-kd_tree.js:2568-2569)
     ctx->Lbar = exp(sum_log / (double)count);
@@ -1007,11 +1044,9 @@ int rt_tone_finish(rt_ctx *ctx, double sum_log, uint64_t count, double *Lbar, do
     ctx->tone_on_device = false;
     if (Lbar) *Lbar = ctx->Lbar;
     if (sf) *sf = ctx->sf;
-    if (!ctx->host_only) {
-        HIPCK(hipSetDevice(ctx->cfg.device));
-        hipLaunchKernelGGL(k_set_tone, dim3(1), dim3(1), 0, ctx->stream, ctx->Lbar, ctx->sf, ctx->d_tone, ctx->d_tone_d);
-        HIPCK(hipGetLastError());
-    }
+    HIPCK(hipSetDevice(ctx->cfg.device));
+    hipLaunchKernelGGL(k_set_tone, dim3(1), dim3(1), 0, ctx->stream, ctx->Lbar, ctx->sf, ctx->d_tone, ctx->d_tone_d);
+    HIPCK(hipGetLastError());
     return 0;
 }
 
@@ -1029,6 +1064,7 @@ int rt_tone_finish_device(rt_ctx *ctx, const void *d_sum_count) {
 
 int rt_tone_get(rt_ctx *ctx, double *Lbar, double *sf) {
     if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_tone_get: host-only context (created with device = -1)");
     if (ctx->tone_on_device) {
         double v[2];
         HIPCK(hipSetDevice(ctx->cfg.device));
@@ -1084,11 +1120,16 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
         (name[6] == 'l' ? ctx->first_level_rays : ctx->first_records) = (uint32_t)value;
         return 0;
     }
+    if (!strcmp(name, "poison_records")) {
+        ctx->poison_records = value != 0.0;
+        return 0;
+    }
     if (!strcmp(name, "stage_timing")) {
         ctx->stage_timing = value != 0.0;
         return 0;
     }
     if (!strcmp(name, "walk_waves_per_cu")) {
+        if (ctx->in_flight) return fail(ctx, "rt_set_option: a frame is in flight, call rt_trace_end first");
         if (!(value >= 1 && value <= 32)) return fail(ctx, "rt_set_option: walk_waves_per_cu must be in 1..32");
         ctx->walk_waves_per_cu = (int)value;
         return 0;
@@ -1098,6 +1139,7 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
 
 int rt_device_rgba8(rt_ctx *ctx, void **dptr, size_t *bytes) {
     if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_device_rgba8: host-only context (created with device = -1)");
     if (dptr) *dptr = ctx->d_rgba;
     if (bytes) *bytes = (size_t)ctx->g.W * ctx->g.H * 4;
     return 0;
@@ -1105,6 +1147,7 @@ int rt_device_rgba8(rt_ctx *ctx, void **dptr, size_t *bytes) {
 
 int rt_device_float(rt_ctx *ctx, void **dptr, size_t *bytes) {
     if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_device_float: host-only context (created with device = -1)");
     if (dptr) *dptr = ctx->d_fb;
     if (bytes) *bytes = (size_t)ctx->g.W * ctx->g.H * 3 * sizeof(float);
     return 0;
@@ -1112,6 +1155,7 @@ int rt_device_float(rt_ctx *ctx, void **dptr, size_t *bytes) {
 
 int rt_device_canvas(rt_ctx *ctx, void **dptr, size_t *bytes) {
     if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_device_canvas: host-only context (created with device = -1)");
     if (dptr) *dptr = ctx->d_canvas;
     if (bytes) *bytes = (size_t)ctx->cfg.width * ctx->cfg.height * 4;
     return 0;
@@ -1119,14 +1163,16 @@ int rt_device_canvas(rt_ctx *ctx, void **dptr, size_t *bytes) {
 
 int rt_device_shard_rgba8(rt_ctx *ctx, void **dptr, size_t *bytes) {
     if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_device_shard_rgba8: host-only context (created with device = -1)");
     if (dptr) *dptr = ctx->d_compact;
-    if (bytes) *bytes = (size_t)ctx->n0 * 4;
+    if (bytes) *bytes = (size_t)ctx->n0 * 4;   // 0 for a shard without tiles (the buffer itself is never smaller than one tile)
     return 0;
 }
 
 int rt_assemble_shards(rt_ctx *ctx, const void *gathered, size_t stride_bytes, int32_t n_shards) {
     if (!ctx) return -1;
     if (ctx->host_only) return fail(ctx, "rt_assemble_shards: host-only context (created with device = -1)");
+    if (ctx->in_flight) return fail(ctx, "rt_assemble_shards: a frame is in flight, call rt_trace_end first");
     if (!gathered || n_shards < 1 || stride_bytes % 256) return fail(ctx, "rt_assemble_shards: bad arguments");
     HIPCK(hipSetDevice(ctx->cfg.device));
     uint32_t stride = (uint32_t)(stride_bytes / 4);

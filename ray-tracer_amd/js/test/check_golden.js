@@ -22,7 +22,15 @@ function extractGenerateScene(text) {
 
 const edits = man.constant_edits || {};
 const opts = { WIDTH: man.width, HEIGHT: man.height, DEVICE: -1 };
-for (const k of Object.keys(edits)) opts[k] = JSON.parse(edits[k]);
+let extra = null;   // a second mesh: "<file> scale <s> translate <x,y,z> ..." as the fixture generator records it
+for (const k of Object.keys(edits)) {
+    if (k === 'meshMaterial') opts.MESH_MATERIAL = edits[k].split(',').map(parseFloat);
+    else if (k === 'extra_mesh') {
+        const m = /^(\S+) scale (\S+) translate (\S+)/.exec(edits[k]);
+        extra = { file: m[1], scale: parseFloat(m[2]), translate: m[3].split(',').map(parseFloat) };
+        opts.REBASE_MESH_INDICES = true;
+    } else opts[k] = JSON.parse(edits[k]);
+}
 const G = rt.createContext(opts);
 const source = pageScript ? extractGenerateScene(fs.readFileSync(pageScript, 'utf8'))
     : fs.readFileSync(path.join(__dirname, '..', 'examples', 'default_scene.js'), 'utf8');
@@ -32,6 +40,18 @@ rt.run(G, source, pageScript || 'default_scene.js');
     const failures = [];
     const data = await G.loadPLY(G.MODEL_FILE_NAME);
     const scene = G.generateScene({ [G.MODEL_FILE_NAME]: data });
+    if (pageScript && opts.MESH_MATERIAL) {   // the page script has the mesh's constants inline: set them afterwards
+        const mat = scene.objects[scene.objects.length - 1].faces[0].getMaterial();
+        ['ka', 'kd', 'ks', 'ke', 'kReflect', 'kRefract', 'ior'].forEach((f, i) => { mat[f] = opts.MESH_MATERIAL[i]; });
+    }
+    if (extra) {
+        const d2 = await (/\.obj$/.test(extra.file) ? G.loadOBJ : G.loadPLY)(extra.file);
+        const m2 = new G.Mesh(G.nextObjectId++, d2.verts, d2.faces);
+        m2.scale(new rt.THREE.Vector3(extra.scale, extra.scale, extra.scale));
+        m2.translate(new rt.THREE.Vector3(...extra.translate));
+        m2.setMaterial(scene.objects[scene.objects.length - 1].faces[0].getMaterial());
+        scene.objects.push(m2);
+    }
     G.animate(scene, man.time);
     const tracer = new G.RayTracer();
     tracer.setScene(scene);
@@ -56,13 +76,9 @@ rt.run(G, source, pageScript || 'default_scene.js');
 
     const k = tracer._meshKey;
     const hashes = { verts_f64: sha(k.verts), verts_f32: sha(new Float32Array(k.verts)), faces_u32: sha(k.faces), face_mat_u32: sha(k.mats) };
-    // the reference stores (type, id, 0) per face in an RGB texture; the fixture hashes that 3-wide layout
-    const mat3 = new Uint32Array(k.mats.length / 2 * 3);
-    for (let i = 0; i < k.mats.length / 2; i++) { mat3[3 * i] = k.mats[2 * i]; mat3[3 * i + 1] = k.mats[2 * i + 1]; }
-    const hashes3 = sha(mat3);
     for (const name of Object.keys(man.sha256)) {
-        if (!(name in hashes)) continue;
-        if (hashes[name] !== man.sha256[name] && !(name === 'face_mat_u32' && hashes3 === man.sha256[name])) failures.push('sha256 ' + name + ' differs');
+        if (!(name in hashes)) failures.push('sha256 ' + name + ' is not checked');
+        else if (hashes[name] !== man.sha256[name]) failures.push('sha256 ' + name + ' differs');
     }
     const kd = tracer.exportKdTree();
     if (kd.nodes.length / 2 !== man.kd.n_nodes) failures.push('k-d node count ' + kd.nodes.length / 2 + ' != ' + man.kd.n_nodes);

@@ -119,7 +119,8 @@ class HipShard:
         self.device = device
         p, n = C.c_void_p(), C.c_size_t()
         rt._ck(rt.L.rt_device_shard_rgba8(rt.ctx, C.byref(p), C.byref(n)), "rt_device_shard_rgba8")
-        self.compact = torch.as_tensor(_DevView(p.value, n.value), device=device)
+        # a shard without tiles (more ranks than tiles) has nothing to copy: no view over zero bytes
+        self.compact = torch.as_tensor(_DevView(p.value, n.value), device=device) if n.value else None
         g_tiles = ((rt.W + 7) // 8) * ((rt.H + 7) // 8)
         sc = max(rt.cfg.shard_count, 1)
         self.stride = ((g_tiles + sc - 1) // sc) * 256
@@ -132,7 +133,8 @@ class HipShard:
         return self.rt.tonePartial()
 
     def shard_bytes(self):
-        self.staging[:self.compact.numel()].copy_(self.compact)
+        if self.compact is not None:
+            self.staging[:self.compact.numel()].copy_(self.compact)
         return self.staging, self.stride
 
     def assemble(self, gathered, stride, world):

@@ -117,6 +117,54 @@ def test_product_kd_builder_bit_exact(ply, gold):
     rt.close()
 
 
+TEAPOT = (model("teapot.obj"), 60.0, (50.0, 75.0, 10.0))
+MESH_MATERIAL = (0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9)
+TWO_MESHES = [("bun_zipper_res4.ply", "k8_res4_teapot_640x480", 640, 480), ("bun_zipper.ply", "c3_bunny_teapot", 3840, 2160)]
+
+
+@pytest.mark.parametrize("ply,gold,w,h", TWO_MESHES)
+def test_two_meshes_obj_ingest_rebase_and_trees_match_reference(ply, gold, w, h):
+    """BASELINE config 3 as benchmarked: bunny + teapot.obj. The fixture comes from the reference's own loadOBJ
+    (js/8-kd_tree.js:2851-2887), Mesh class and builder; only the index rebase of the second mesh is the harness's.
+    scene.load_obj + mesh_arrays(rebase=True), the oracle builder and the product builder reproduce every array."""
+    m = manifest(gold)
+    assert "teapot.obj" in m["constant_edits"]["extra_mesh"]
+    flat = make_flat(ply, w, h, depth=5, mesh_material=MESH_MATERIAL, extra_mesh=TEAPOT)
+    v, f, fm = flat.verts, flat.faces, flat.face_mat
+    assert (len(v), len(f)) == (m["n_verts"], m["n_faces"])
+    assert sha(v) == m["sha256"]["verts_f64"] and sha(v.astype(np.float32)) == m["sha256"]["verts_f32"]
+    assert sha(f) == m["sha256"]["faces_u32"] and sha(fm) == m["sha256"]["face_mat_u32"]
+    full = os.path.join(GOLDEN, gold, "verts_f64.bin")
+    if os.path.exists(full):
+        assert np.array_equal(v.ravel(), np.fromfile(full, np.float64))
+        assert np.array_equal(f.ravel(), np.fromfile(os.path.join(GOLDEN, gold, "faces_u32.bin"), np.uint32))
+    # the teapot's faces are (3k, 3k+1, 3k+2) behind the bunny's vertices
+    n_bunny_v = len(scene.load_ply(model(ply))[0])
+    tf = f[f.min(axis=1) >= n_bunny_v]
+    assert len(tf) == 2464 and np.array_equal(tf.ravel(), np.arange(n_bunny_v, n_bunny_v + 3 * 2464, dtype=np.uint32))
+    kd = m["kd"]
+    pairs, leaves, box, depth = oracle.kd_build(v, f)
+    assert (len(pairs), len(leaves), depth) == (kd["n_nodes"], kd["n_leaves"], kd["depth"])
+    assert sha(pairs) == kd["sha256"]["nodes_sparse_u32"] and sha(leaves) == kd["sha256"]["leaves_i32"]
+    assert sha(box) == kd["sha256"]["root_box_f64"]
+    rt = abi.RayTracerHIP(abi.default_config(device=-1))
+    rt.setMesh(v, f, fm)
+    rt.buildKdTree()
+    pp, pl, pb = rt.exportKdTree()
+    rt.close()
+    assert sha(pp) == kd["sha256"]["nodes_sparse_u32"] and sha(pl) == kd["sha256"]["leaves_i32"] and sha(pb) == kd["sha256"]["root_box_f64"]
+    # uniforms of the benchmarked scene: mesh material constants, box, camera rays at the fixture's canvas size
+    U = uniforms(m)
+    mesh_mat = flat.mats[-1]
+    for key, val in zip(("ka", "kd", "ks", "ke", "kReflect", "kRefract", "ior"), mesh_mat[2:9]):
+        assert f32(val) == f32(U["phongMaterials[%d].%s" % (mesh_mat[1], key)][0]), key
+    assert np.array_equal(f32(box[:3]), f32(U["kdBoxMin"])) and np.array_equal(f32(box[3:]), f32(U["kdBoxMax"]))
+    for n in ("ray00", "ray01", "ray10", "ray11"):
+        assert np.array_equal(getattr(flat, n), f32(U[n])), n
+    assert m["glsl_counts"]["ray_tree_size"] == 2 ** int(m["constant_edits"]["MAX_RECURSION_DEPTH"]) - 1
+    assert m["glsl_counts"]["num_faces"] == len(f)
+
+
 def test_kd_edge_cases():
     rt = abi.RayTracerHIP(abi.default_config(device=-1))
     # empty mesh: a single EMPTY_LEAF root, no leaves

@@ -31,15 +31,17 @@ def run_node(args, timeout=300):
 
 
 @needs_node
-@pytest.mark.parametrize("golden", ["k8_res4_640x480", "k8_res3_640x480", "c2_res4_1920x1080", "k8_full_640x480"])
+@pytest.mark.parametrize("golden", ["k8_res4_640x480", "k8_res3_640x480", "c2_res4_1920x1080", "k8_full_640x480",
+                                    "k8_res4_teapot_640x480", "c3_bunny_teapot"])
 def test_js_scene_matches_reference_capture(golden):
+    """The two *teapot fixtures add a second mesh through loadOBJ with REBASE_MESH_INDICES (BASELINE config 3 as benchmarked)."""
     out = run_node([os.path.join(JS, "test", "check_golden.js"), os.path.join(GOLDEN, golden)])
     assert out["failures"] == [] and out["uniforms_checked"] >= 80
 
 
 @needs_node
 @pytest.mark.skipif(not os.path.exists(REF_SCRIPT), reason="reference checkout not present")
-@pytest.mark.parametrize("golden", ["k8_res4_640x480", "c2_res4_1920x1080"])
+@pytest.mark.parametrize("golden", ["k8_res4_640x480", "c2_res4_1920x1080", "k8_res4_teapot_640x480"])
 def test_unchanged_reference_generate_scene_runs(golden):
     """generateScene() is read from the reference's page script at test time and evaluated as it is."""
     out = run_node([os.path.join(JS, "test", "check_golden.js"), os.path.join(GOLDEN, golden), REF_SCRIPT])
