@@ -131,8 +131,9 @@ void rt_default_config(rt_config *cfg);
 
 /* ---- scene: replaces the uniform marshalling of RayTracer.update (js/8-kd_tree.js:2435-2453,
  *      :1104-1126) and the shader regeneration of RayTracer.setScene (:2347-2431) --------
- * Every call that changes the scene, the mesh, the tree or the walk's launch shape fails between rt_trace_begin and
- * rt_trace_end: the queued frame still reads them. */
+ * These calls and rt_set_mesh / rt_build_kdtree change host-side copies only; the device tables are refreshed by the
+ * next rt_trace_begin, so they may be called while a frame is in flight. rt_build_kdtree_device replaces device arrays
+ * the queued frame still reads and therefore fails between rt_trace_begin and rt_trace_end. */
 int rt_set_primitives(rt_ctx *ctx, const rt_prim *prims, int32_t n);
 int rt_set_materials(rt_ctx *ctx, const rt_material *mats, int32_t n);
 /* n_loop is the trip count of the light loop baked into the shader (`nextPointLightId`,

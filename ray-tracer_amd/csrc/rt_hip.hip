@@ -99,7 +99,8 @@ struct rt_ctx {
     GpuKdBuilder *gpu_kd = nullptr;              // device-side builder and its tree (rt_build_kdtree_device)
     bool kd_on_device = false;                   // the current tree is gpu_kd->tree, not `kd`
     bool kd_built = false, scene_dirty = true, mesh_dirty = true;
-    SceneDev sh{};   // host mirror of the device scene header
+    SceneDev sh{};   // host mirror of the device scene header, as the frame in flight (and a repeat of it) uses it
+    struct { float ambient[4], bg[4], cam[4], r00[4], r01[4], r10[4], r11[4]; } next{};   // rt_set_globals / rt_set_camera: taken over by the next rt_trace_begin
     // device
     SceneDev *d_scene = nullptr;
     PrimDev *d_prims = nullptr;
@@ -333,6 +334,9 @@ int upload_scene(rt_ctx *ctx) {
 
     SceneDev &h = ctx->sh;
     const rt_config &c = ctx->cfg;
+    memcpy(h.ambient, ctx->next.ambient, sizeof h.ambient); memcpy(h.bg, ctx->next.bg, sizeof h.bg);
+    memcpy(h.cam, ctx->next.cam, sizeof h.cam); memcpy(h.r00, ctx->next.r00, sizeof h.r00); memcpy(h.r01, ctx->next.r01, sizeof h.r01);
+    memcpy(h.r10, ctx->next.r10, sizeof h.r10); memcpy(h.r11, ctx->next.r11, sizeof h.r11);
     h.n_prims = (int32_t)ctx->prims.size();
     h.n_mats = (int32_t)ctx->mats.size();
     h.n_lights = (int32_t)ctx->lights.size();
@@ -519,7 +523,6 @@ void rt_destroy(rt_ctx *ctx) {
 int rt_set_primitives(rt_ctx *ctx, const rt_prim *prims, int32_t n) {
     if (!ctx) return -1;
     if (n < 0 || (n > 0 && !prims)) return fail(ctx, "rt_set_primitives: bad arguments");
-    if (ctx->in_flight) return fail(ctx, "rt_set_primitives: a frame is in flight, call rt_trace_end first");
     if (n > 60000) return fail(ctx, "rt_set_primitives: at most 60000 primitives");
     for (int i = 0; i < n; i++)
         if (prims[i].kind < RT_PRIM_PLANE || prims[i].kind > RT_PRIM_CYLINDER) return fail(ctx, "rt_set_primitives: unknown primitive kind");
@@ -533,7 +536,6 @@ int rt_set_primitives(rt_ctx *ctx, const rt_prim *prims, int32_t n) {
 int rt_set_materials(rt_ctx *ctx, const rt_material *mats, int32_t n) {
     if (!ctx) return -1;
     if (n < 0 || (n > 0 && !mats)) return fail(ctx, "rt_set_materials: bad arguments");
-    if (ctx->in_flight) return fail(ctx, "rt_set_materials: a frame is in flight, call rt_trace_end first");
     for (int i = 0; i < n; i++)
         if (mats[i].type < RT_MAT_PHONG || mats[i].type > RT_MAT_PHONG_CHECKERED) return fail(ctx, "rt_set_materials: unknown material type");
     if ((size_t)n == ctx->mats_host.size() && (n == 0 || memcmp(mats, ctx->mats_host.data(), (size_t)n * sizeof(rt_material)) == 0)) return 0;
@@ -546,7 +548,6 @@ int rt_set_materials(rt_ctx *ctx, const rt_material *mats, int32_t n) {
 int rt_set_lights(rt_ctx *ctx, const rt_light *lights, int32_t n, int32_t n_loop) {
     if (!ctx) return -1;
     if (n < 0 || (n > 0 && !lights) || n_loop < n) return fail(ctx, "rt_set_lights: bad arguments (need n >= 0, n_loop >= n)");
-    if (ctx->in_flight) return fail(ctx, "rt_set_lights: a frame is in flight, call rt_trace_end first");
     if (n_loop > MAX_LIGHTS) return fail(ctx, "rt_set_lights: at most 32 lights");
     ctx->lights.assign((size_t)n_loop, LightDev{{0, 0, 0, 0}, {0, 0, 0, 0}});
     for (int i = 0; i < n; i++)
@@ -558,8 +559,7 @@ int rt_set_lights(rt_ctx *ctx, const rt_light *lights, int32_t n, int32_t n_loop
 int rt_set_globals(rt_ctx *ctx, const float ambient[3], const float bg[3]) {
     if (!ctx) return -1;
     if (!ambient || !bg) return fail(ctx, "rt_set_globals: null argument");
-    if (ctx->in_flight) return fail(ctx, "rt_set_globals: a frame is in flight, call rt_trace_end first");
-    for (int k = 0; k < 3; k++) { ctx->sh.ambient[k] = ambient[k]; ctx->sh.bg[k] = bg[k]; }
+    for (int k = 0; k < 3; k++) { ctx->next.ambient[k] = ambient[k]; ctx->next.bg[k] = bg[k]; }
     ctx->scene_dirty = true;
     return 0;
 }
@@ -568,9 +568,8 @@ int rt_set_camera(rt_ctx *ctx, const float pos[3], const float r00[3], const flo
                   const float r11[3]) {
     if (!ctx) return -1;
     if (!pos || !r00 || !r01 || !r10 || !r11) return fail(ctx, "rt_set_camera: null argument");
-    if (ctx->in_flight) return fail(ctx, "rt_set_camera: a frame is in flight, call rt_trace_end first");
     for (int k = 0; k < 3; k++) {
-        ctx->sh.cam[k] = pos[k]; ctx->sh.r00[k] = r00[k]; ctx->sh.r01[k] = r01[k]; ctx->sh.r10[k] = r10[k]; ctx->sh.r11[k] = r11[k];
+        ctx->next.cam[k] = pos[k]; ctx->next.r00[k] = r00[k]; ctx->next.r01[k] = r01[k]; ctx->next.r10[k] = r10[k]; ctx->next.r11[k] = r11[k];
     }
     ctx->scene_dirty = true;
     return 0;
@@ -581,7 +580,6 @@ int rt_set_mesh(rt_ctx *ctx, const double *verts, int32_t n_verts, const uint32_
     if (!ctx) return -1;
     if (n_verts < 0 || n_faces < 0 || (n_verts > 0 && !verts) || (n_faces > 0 && (!faces || !face_mat)))
         return fail(ctx, "rt_set_mesh: bad arguments");
-    if (ctx->in_flight) return fail(ctx, "rt_set_mesh: a frame is in flight, call rt_trace_end first");
     for (int64_t i = 0; i < (int64_t)n_faces * 3; i++)
         if (faces[i] >= (uint32_t)n_verts) return fail(ctx, "rt_set_mesh: face index out of range");
     ctx->verts.assign(verts, verts + (size_t)n_verts * 3);
@@ -612,7 +610,6 @@ int rt_build_kdtree_device(rt_ctx *ctx) {
 
 int rt_build_kdtree(rt_ctx *ctx) {
     if (!ctx) return -1;
-    if (ctx->in_flight) return fail(ctx, "rt_build_kdtree: a frame is in flight, call rt_trace_end first");
     if (ctx->kd_on_device) { ctx->kd_on_device = false; ctx->mesh_dirty = true; }
     auto t0 = std::chrono::steady_clock::now();
     build_kdtree(ctx->verts.data(), (int64_t)ctx->verts.size() / 3, ctx->faces.data(), (int64_t)ctx->faces.size() / 3,
@@ -1129,8 +1126,7 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
         return 0;
     }
     if (!strcmp(name, "walk_waves_per_cu")) {
-        if (ctx->in_flight) return fail(ctx, "rt_set_option: a frame is in flight, call rt_trace_end first");
-        if (!(value >= 1 && value <= 32)) return fail(ctx, "rt_set_option: walk_waves_per_cu must be in 1..32");
+            if (!(value >= 1 && value <= 32)) return fail(ctx, "rt_set_option: walk_waves_per_cu must be in 1..32");
         ctx->walk_waves_per_cu = (int)value;
         return 0;
     }
@@ -1172,7 +1168,6 @@ int rt_device_shard_rgba8(rt_ctx *ctx, void **dptr, size_t *bytes) {
 int rt_assemble_shards(rt_ctx *ctx, const void *gathered, size_t stride_bytes, int32_t n_shards) {
     if (!ctx) return -1;
     if (ctx->host_only) return fail(ctx, "rt_assemble_shards: host-only context (created with device = -1)");
-    if (ctx->in_flight) return fail(ctx, "rt_assemble_shards: a frame is in flight, call rt_trace_end first");
     if (!gathered || n_shards < 1 || stride_bytes % 256) return fail(ctx, "rt_assemble_shards: bad arguments");
     HIPCK(hipSetDevice(ctx->cfg.device));
     uint32_t stride = (uint32_t)(stride_bytes / 4);
