@@ -217,11 +217,11 @@ def main():
         "frames_in_flight": n_ctx, "frame_job": "pipelined (stream-ordered, device-resident exchange)" if pipelined else "host-synchronised",
         "frames_retraced": getattr(frame, "redone", 0),
         "step_kernel_ms": [round(float(x), 4) for x in lvl_ms[:args.depth + 1]],
-        "stage_names": ["k_gen_prims", "k_kd_walk", "k_tri_test", "k_shade_b", "k_shade_a"],
-        "pipeline_step": "step k = k_gen_prims(level k), k_kd_walk + k_tri_test (closest-hit rays of level k with the shadow rays of level k-1), k_shade_b(level k-1), k_shade_a(level k)",
+        "stage_names": ["k_gen_prims", "k_kd_walk", "k_shade_b", "k_shade_a"],
+        "pipeline_step": "step k = k_gen_prims(level k), k_kd_walk (closest-hit rays of level k with the shadow rays of level k-1, triangle tests inside the walk), k_shade_b(level k-1), k_shade_a(level k)",
         "tri_records": [int(x) for x in st.tri_records],
-        "step_stage_ms": [[round(float(x), 4) for x in row[:5]] for row in stage_ms[:args.depth + 1]],
-        "stage_ms": [round(float(x), 4) for x in stage_ms.sum(axis=0)[:5]],
+        "step_stage_ms": [[round(float(x), 4) for x in row[:4]] for row in stage_ms[:args.depth + 1]],
+        "stage_ms": [round(float(x), 4) for x in stage_ms.sum(axis=0)[:4]],
         "kd_closest_rays": int(st.kd_closest_rays), "kd_shadow_rays": int(st.kd_shadow_rays),
         "kd_build_ms": st.kd_build_ms, "kd_upload_ms": st.kd_upload_ms, "scene_setup_s": setup_s,
     }

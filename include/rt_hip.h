@@ -106,13 +106,13 @@ typedef struct rt_stats {
     uint64_t shadow_rays;       /* lights x shaded nodes */
     uint64_t pixels;            /* pixels of this shard (supersampled resolution) */
     double   trace_ms;          /* device time of the whole trace (all steps + composite) */
-    /* A frame of depth D runs as D+1 pipeline steps. Step k: analytic closest hit of level k, k-d walk and
+    /* A frame of depth D runs as D+1 pipeline steps. Step k: analytic closest hit of level k, k-d walk with its
      * triangle tests (closest-hit rays of level k together with the shadow rays of level k-1), shading of
      * level k-1, hit resolution + children + shadow-ray set-up of level k. Step 8 (depth 8 only) is not itemised. */
-    double   level_kernel_ms[8];/* device time of one step (all five stages) */
-    double   level_stage_ms[8][7]; /* per step, columns 0..4: k_gen_prims, k_kd_walk, k_tri_test, k_shade_b, k_shade_a; 5..6 unused */
+    double   level_kernel_ms[8];/* device time of one step (all four stages) */
+    double   level_stage_ms[8][7]; /* per step, columns 0..3: k_gen_prims, k_kd_walk, k_shade_b, k_shade_a; 4..6 unused */
     double   stage_ms[7];       /* the same, summed over all steps */
-    uint64_t tri_records[2];    /* (ray, triangle) records listed by the closest / shadow walks */
+    uint64_t tri_records[2];    /* (ray, non-empty leaf) records whose triangles the closest / shadow walks tested */
     uint64_t kd_closest_rays;   /* rays that walked the k-d tree for a closest hit */
     uint64_t kd_shadow_rays;    /* shadow rays that walked the k-d tree */
     double   composite_ms;      /* device time of the bottom-up colour accumulation */
@@ -236,11 +236,9 @@ int rt_stream(rt_ctx *ctx, void **stream);
 /* Tuning knobs by name. "walk_waves_per_cu" (1..32, default 24): persistent waves per compute unit of the k-d walk;
  * two contexts that trace concurrently on one GPU fit side by side at 12. "stage_timing" (0 / 1, default 1): HIP events
  * around every stage kernel, which fill rt_stats.level_stage_ms / stage_ms / level_kernel_ms; without them those
- * fields are zero and a frame is about forty queue entries shorter. "first_level_rays" / "first_records" (0 = default):
- * capacity of the deeper ray-tree levels / of the leaf-record buffers on a context's first frame; later frames use what
- * the earlier ones needed (a frame that does not fit is traced again, see rt_trace_end). "poison_records" (0 / 1, test
- * hook): leaf-record buffers are filled with 0xff bytes when they are allocated, so that a kernel reading a record no
- * walk wrote shows up as a fault or a wrong image instead of going unnoticed. No counterpart in the reference. */
+ * fields are zero and a frame is about thirty queue entries shorter. "first_level_rays" (0 = default): capacity of the
+ * deeper ray-tree levels on a context's first frame; later frames use what the earlier ones needed (a frame that does
+ * not fit is traced again, see rt_trace_end). No counterpart in the reference. */
 int rt_set_option(rt_ctx *ctx, const char *name, double value);
 
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);

@@ -23,10 +23,10 @@ namespace {
 
 thread_local std::string g_create_error;
 
-// Pipeline step k of a frame: k_gen_prims(level k), k_kd_walk + k_tri_test (closest-hit rays of level k together with
-// the shadow rays of level k-1), k_shade_b(level k-1), k_shade_a(level k). A frame of depth D takes D+1 steps; the
-// last one only finishes the shadow rays of the last level.
-constexpr int N_STAGES = 5;
+// Pipeline step k of a frame: k_gen_prims(level k), k_kd_walk (closest-hit rays of level k together with the shadow
+// rays of level k-1, triangle tests included), k_shade_b(level k-1), k_shade_a(level k). A frame of depth D takes D+1
+// steps; the last one only finishes the shadow rays of the last level.
+constexpr int N_STAGES = 4;
 constexpr int MAX_STEPS = MAX_LEVELS + 1;
 
 // ------------------------------------------------------------------------------------------------
@@ -38,13 +38,6 @@ struct Level {
 
 constexpr int MAX_PARTS = 8;
 
-// A walking wave reserves leaf records in chunks of REC_CHUNK and writes nothing into a chunk that would cross the end
-// of the buffer, so only whole chunks are ever written: this is the capacity the walk, the triangle tests and the
-// overflow check all use (a tail shorter than a chunk would be read by the tests without ever being written).
-inline uint32_t usable_records(size_t cap) {
-    return (uint32_t)(std::min<size_t>(cap, 0x3fffff00u) / (size_t)REC_CHUNK * (size_t)REC_CHUNK);
-}
-
 // One independent slice of the shard's tiles. Every part has its own stream, ray-tree levels, queues, record
 // buffer and counters, so the parts of a frame run concurrently: while the last long rays of one part's walk
 // drain (a persistent kernel ends only when its slowest ray does), the other parts' kernels fill the machine.
@@ -53,7 +46,6 @@ struct Part {
     hipEvent_t ev[MAX_STEPS][N_STAGES + 1]{};    // stage boundaries of every step
     hipEvent_t ev_begin = nullptr, ev_comp = nullptr, ev_end = nullptr, ev_counts = nullptr;
     uint32_t want[MAX_LEVELS]{};                 // capacity the next frame gives level l (0 = not known yet)
-    size_t want_recs[2] = {0, 0};
     Level lv[MAX_LEVELS];
     LevelCounters *d_counts = nullptr;           // one block of counters per level
     LevelCounters *h_counts = nullptr;           // pinned host copy
@@ -62,9 +54,7 @@ struct Part {
     void *d_shq_mem[2] = {nullptr, nullptr};     // shadow traversal queues: level l uses queue l & 1 (the queue of
     ShadowQ shq[2]{};                            // level l-1 is still being walked while level l fills its own)
     uint32_t cap_shq[2] = {0, 0};
-    uint2 *d_recs[2] = {nullptr, nullptr};       // leaf records of the closest-hit walk / of the shadow walk in flight
-    size_t cap_recs[2] = {0, 0};
-    uint64_t rec_total[2] = {0, 0};              // records written this frame (statistics)
+    uint64_t rec_total[2] = {0, 0};              // leaf records tested this frame by the closest-hit / shadow walks (statistics)
     uint32_t n_rays[MAX_LEVELS]{};
     FrameGeom g{};
     uint32_t n0 = 0;                             // level-0 entries = tiles of this part * 64
@@ -80,8 +70,7 @@ struct rt_ctx {
     hipEvent_t ev_misc[2]{};                     // tone begin / end
     int n_cus = 256;
     int walk_waves_per_cu = RT_WALK_WAVES_PER_CU;
-    uint32_t first_level_rays = 0, first_records = 0;   // sizes of the first frame's buffers (0 = defaults), rt_set_option
-    bool poison_records = false;                 // test hook: new leaf-record buffers are filled with 0xff instead of left as allocated
+    uint32_t first_level_rays = 0;               // capacity of the deeper levels on the first frame (0 = level 0's), rt_set_option
     bool stage_timing = true;                    // events around every stage kernel (rt_stats.level_stage_ms)
     bool stage_timed = false;                    // the frame in flight was queued with them
     int n_parts = 1;
@@ -220,6 +209,7 @@ int device_build(rt_ctx *ctx) {
         ctx->err = "rt_build_kdtree_device: " + err;
         return -1;
     }
+    if (ctx->gpu_kd->tree.n_slots > (1u << RING_SLOT_BITS)) return fail(ctx, "rt_build_kdtree_device: k-d tree has too many leaf slots for the device layout (2^24)");
     ctx->st.kd_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->st.kd_upload_ms = 0.0;
     return 0;
@@ -294,7 +284,7 @@ int upload_scene(rt_ctx *ctx) {
             for (int k = 0; k < 4; k++) c += kd.leaves[i].face[k] > -1;
             first[i + 1] = first[i] + c;
         }
-        if (first.back() > LEAF_SLOT_MASK) return fail(ctx, "k-d tree has too many leaf slots for the device layout");
+        if (first.back() > (1u << RING_SLOT_BITS)) return fail(ctx, "k-d tree has too many leaf slots for the device layout (2^24)");
         std::vector<TriDev> ltris(first.back());
         for (size_t i = 0; i < kd.leaves.size(); i++) {
             uint32_t s0 = first[i];
@@ -505,7 +495,7 @@ void rt_destroy(rt_ctx *ctx) {
     for (auto &ev : ctx->ev_misc)
         if (ev) (void)hipEventDestroy(ev);
     for (Part &P : ctx->parts) {
-        for (void *p : {(void *)P.d_counts, (void *)P.d_kdq, (void *)P.d_recs[0], (void *)P.d_recs[1], P.d_shq_mem[0], P.d_shq_mem[1]})
+        for (void *p : {(void *)P.d_counts, (void *)P.d_kdq, P.d_shq_mem[0], P.d_shq_mem[1]})
             if (p) (void)hipFree(p);
         if (P.h_counts) (void)hipHostFree(P.h_counts);
         for (auto &l : P.lv)
@@ -699,8 +689,6 @@ static int launch_step(rt_ctx *ctx, Part &P, int k) {
         J.kdq = P.d_kdq;
         J.best = P.lv[k].b.best;
         J.cnt = P.d_counts + k;
-        J.recs = P.d_recs[0];
-        J.rec_cap = usable_records(P.cap_recs[0]);
         J.enabled = walk ? 1u : 0u;
     }
     if (have_prev) {
@@ -710,8 +698,6 @@ static int launch_step(rt_ctx *ctx, Part &P, int k) {
         J.shq_id = P.shq[(k - 1) & 1].id;
         J.shadow = P.lv[k - 1].b.shadow;
         J.cnt = P.d_counts + (k - 1);
-        J.recs = P.d_recs[1];
-        J.rec_cap = usable_records(P.cap_recs[1]);
         J.q_cap = P.cap_shq[(k - 1) & 1];
         J.enabled = walk ? 1u : 0u;
     }
@@ -719,7 +705,6 @@ static int launch_step(rt_ctx *ctx, Part &P, int k) {
     const dim3 grid((A.n_rays + BLOCK - 1) / BLOCK), grid_prev((B.n_rays + BLOCK - 1) / BLOCK);
     // persistent traversal waves: one 64-lane workgroup each (LDS: short stacks + mailbox)
     const dim3 walk_grid((unsigned)ctx->n_cus * (unsigned)ctx->walk_waves_per_cu);
-    const dim3 test_grid((unsigned)ctx->n_cus * 32u);   // grid-stride over the records
     const bool any_walk = Wk.job[0].enabled || Wk.job[1].enabled;
     hipEvent_t *ev = P.ev[k];
     if (ctx->stage_timing) HIPCK(hipEventRecord(ev[0], s));
@@ -727,13 +712,11 @@ static int launch_step(rt_ctx *ctx, Part &P, int k) {
     if (ctx->stage_timing) HIPCK(hipEventRecord(ev[1], s));
     if (any_walk) hipLaunchKernelGGL(k_kd_walk, walk_grid, dim3(WAVE), 0, s, Wk);
     if (ctx->stage_timing) HIPCK(hipEventRecord(ev[2], s));
-    if (any_walk) hipLaunchKernelGGL(k_tri_test, test_grid, dim3(256), 0, s, Wk);
-    if (ctx->stage_timing) HIPCK(hipEventRecord(ev[3], s));
     if (have_prev) hipLaunchKernelGGL(k_shade_b, grid_prev, dim3(BLOCK), 0, s, B);
-    if (ctx->stage_timing) HIPCK(hipEventRecord(ev[4], s));
+    if (ctx->stage_timing) HIPCK(hipEventRecord(ev[3], s));
     if (have_cur) hipLaunchKernelGGL(k_shade_a, grid, dim3(BLOCK), 0, s, A);
     HIPCK(hipGetLastError());
-    if (ctx->stage_timing) HIPCK(hipEventRecord(ev[5], s));
+    if (ctx->stage_timing) HIPCK(hipEventRecord(ev[4], s));
     return 0;
 }
 
@@ -743,7 +726,6 @@ static int launch_step(rt_ctx *ctx, Part &P, int k) {
 static int enqueue_part(rt_ctx *ctx, Part &P) {
     const int D = ctx->cfg.max_depth;
     const SceneDev &sh = ctx->sh;
-    const bool walk = sh.render_triangles && sh.use_kd;
     hipStream_t s = P.stream;
     HIPCK(hipMemsetAsync(P.d_counts, 0, MAX_LEVELS * sizeof(LevelCounters), s));
     HIPCK(hipEventRecord(P.ev_begin, s));
@@ -759,15 +741,6 @@ static int enqueue_part(rt_ctx *ctx, Part &P) {
     }
     for (int l = 0; l < D; l++)
         if (ensure_queues(ctx, P, l, P.lv[l].cap, (uint32_t)sh.n_lights)) return -1;
-    if (walk)
-        for (int j = 0; j < 2; j++) {
-            if (P.want_recs[j] == 0) P.want_recs[j] = ctx->first_records ? ctx->first_records : std::max<size_t>((size_t)8 << 20, (size_t)P.n0 * 8);
-            P.want_recs[j] = (P.want_recs[j] + (size_t)REC_CHUNK - 1) / (size_t)REC_CHUNK * (size_t)REC_CHUNK;
-            const uint2 *before = P.d_recs[j];
-            if (ensure(ctx, P.d_recs[j], P.cap_recs[j], P.want_recs[j])) return -1;
-            if (ctx->poison_records && P.d_recs[j] != before)
-                HIPCK(hipMemsetAsync(P.d_recs[j], 0xff, P.cap_recs[j] * sizeof(uint2), s));
-        }
     for (int k = 0; k <= D; k++)
         if (launch_step(ctx, P, k)) return -1;
     HIPCK(hipEventRecord(P.ev_comp, s));
@@ -785,13 +758,11 @@ static int enqueue_part(rt_ctx *ctx, Part &P) {
     return 0;
 }
 
-// Waits for the part's frame and checks the counters: children beyond a level's capacity were dropped, leaf records
-// beyond the buffer were not written. Either makes the frame wrong, so the buffers are grown to what the counters ask
-// for and 1 is returned: the caller queues the frame again. (Counts below a level that overflowed are too low; a
-// later attempt sees them.)
+// Waits for the part's frame and checks the counters: children beyond a level's capacity were dropped. That makes the
+// frame wrong, so the levels are grown to what the counters ask for and 1 is returned: the caller queues the frame
+// again. (Counts below a level that overflowed are too low; a later attempt sees them.)
 static int finish_part(rt_ctx *ctx, Part &P) {
     const int D = ctx->cfg.max_depth;
-    const bool walk = ctx->sh.render_triangles && ctx->sh.use_kd;
     HIPCK(hipEventSynchronize(P.ev_counts));
     memset(P.n_rays, 0, sizeof P.n_rays);
     P.levels_run = 0;
@@ -799,7 +770,6 @@ static int finish_part(rt_ctx *ctx, Part &P) {
     if (P.n0 == 0) return 0;
     bool again = false;
     P.n_rays[0] = P.n0;
-    size_t need_recs[2] = {0, 0};
     for (int l = 0; l < D; l++) {
         if (P.n_rays[l] == 0) break;
         P.levels_run = l + 1;
@@ -817,16 +787,9 @@ static int finish_part(rt_ctx *ctx, Part &P) {
             }
             P.n_rays[l + 1] = std::min(hc.next_count, P.lv[l + 1].cap);
         }
-        for (int j = 0; j < 2; j++) need_recs[j] = std::max<size_t>(need_recs[j], hc.rec_count[j]);
         P.rec_total[0] += hc.rec_count[0];
         P.rec_total[1] += hc.rec_count[1];
     }
-    for (int j = 0; j < 2 && walk; j++)
-        if (need_recs[j] > usable_records(P.cap_recs[j])) {
-            if (need_recs[j] > usable_records(0x3fffff00u)) return fail(ctx, "rt_trace: leaf record buffer cannot hold one level");
-            P.want_recs[j] = std::min<size_t>(need_recs[j] + need_recs[j] / 4, 0x3fffff00u);
-            again = true;
-        }
     return again ? 1 : 0;
 }
 
@@ -1112,13 +1075,9 @@ int rt_stream(rt_ctx *ctx, void **stream) {
 int rt_set_option(rt_ctx *ctx, const char *name, double value) {
     if (!ctx) return -1;
     if (!name) return fail(ctx, "rt_set_option: null name");
-    if (!strcmp(name, "first_level_rays") || !strcmp(name, "first_records")) {
+    if (!strcmp(name, "first_level_rays")) {
         if (!(value >= 0 && value <= 2147483392.0)) return fail(ctx, "rt_set_option: capacity out of range");
-        (name[6] == 'l' ? ctx->first_level_rays : ctx->first_records) = (uint32_t)value;
-        return 0;
-    }
-    if (!strcmp(name, "poison_records")) {
-        ctx->poison_records = value != 0.0;
+        ctx->first_level_rays = (uint32_t)value;
         return 0;
     }
     if (!strcmp(name, "stage_timing")) {

@@ -69,7 +69,7 @@ struct LevelCounters {
     uint32_t shq_head, pad3[31];
     uint32_t next_count, pad4[31];
     uint32_t shaded, pad5[31];
-    uint32_t rec_count[2], pad6[30];      // triangle records written by the closest / shadow walk
+    uint32_t rec_count[2], pad6[30];      // leaf records tested by the closest / shadow walk (statistics)
     unsigned long long walk_iters[2], walk_visits[2], walk_t0[2], walk_t1[2], walk_tsum[2], pad7[6];   // RT_WALK_STATS builds only: wave iterations, lane node visits, first start / last end / summed lifetime of the waves (100 MHz ticks)
 };
 
@@ -80,12 +80,11 @@ struct LevelArgs {
     LevelBuf cur, nxt;
     ShadowQ shq;
     uint4 *kdq;             // closest-hit traversal queue: (ray index, root-box entry distance, exit distance, -)
-    const uint2 *recs;      // triangle records of the closest walk (k_shade_a resolves the winner)
     LevelCounters *cnt;
     const uint32_t *n_src;  // levels below 0: where the parent level counted its children (read on the device, so that
                             // the host can queue a whole frame without waiting for any count); null = n_rays is exact
     uint32_t n_rays;        // entries of this level, or with n_src the capacity that bounds the count
-    uint32_t nxt_cap, shq_cap, rec_cap;
+    uint32_t nxt_cap, shq_cap;
     int32_t *hit_ids;       // level 0 only, full frame
     FrameGeom g;
     int32_t level, last_level;
@@ -226,12 +225,28 @@ __global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
 // entry. When the ring runs dry although the ray has not reached the end of the root interval, the walk
 // restarts at the root with kdTMin = the end of the cell just finished - what the reference does after EVERY
 // cell - so a restart re-derives exactly the dropped decisions.
-// Every lane owns one ray and takes one tree action per iteration (a descent step, or at a leaf: list its
+// Every lane owns one ray and takes one tree action per iteration (a descent step, or at a leaf: note its
 // triangles and pop); a lane whose ray is finished pulls the next one from the global queue.
-// The walk and the triangle tests of one pipeline step serve two queues in one launch: job 0 = the shadow rays of
-// the previous ray-tree level, job 1 = the closest-hit rays of the current one. The two are independent (the
-// children of a level are spawned before its shadow rays are walked), and one launch lets the waves that run out
-// of shadow rays move straight on to the closest-hit queue instead of idling until the slowest shadow ray is done.
+//
+// Triangle tests. A lane at a non-empty leaf does not test the leaf's faces itself (the other 63 lanes would idle
+// meanwhile): it appends a 4-byte record (its lane, the leaf's slot range) to a ring in LDS that the wave shares.
+// As soon as the ring holds 64 records, the whole wave stops walking for one round and every lane tests one
+// record - the ray of the record's lane comes through ds_bpermute from that lane's registers, the triangles
+// from the leaf-ordered table - so the Moller-Trumbore code always runs with full lanes and no record ever
+// leaves the compute unit. Closest hit: the shader tests a leaf's faces in order and keeps a hit only if
+// `hitInfo.t < tMin` (js/8-kd_tree.js:948-949), i.e. among equal distances the face met FIRST wins; a 64-bit key
+// (t bits, visit rank of the leaf for this ray, face position in the leaf) ordered by an atomic min reproduces that
+// without any assumption on the order of the tests, and names the winner: rank ^ near_upper_levels(direction) is the
+// leaf's path code, SceneDev::path_slot maps it to the leaf's slots. Shadow rays: any hit sets the light's bit of the
+// ray, and the lane that owns the ray is told through LDS and drops the ray - the reference's early return
+// (js/8-kd_tree.js:685-687); where the walk stops changes no result because every hit sets the same bit.
+// A lane whose records are still in the ring keeps its ray registers: it takes no new ray from the queue and no
+// stretch from a neighbour until the ring's head has passed its last record.
+//
+// One launch serves two queues: job 0 = the shadow rays of the previous ray-tree level, job 1 = the closest-hit rays
+// of the current one. The two are independent (the children of a level are spawned before its shadow rays are
+// walked), and one launch lets the waves that run out of shadow rays move straight on to the closest-hit queue
+// instead of idling until the slowest shadow ray is done.
 struct WalkJob {
     const float4 *rays;        // job 0: shadow queue records (origin + entry distance, direction + exit distance); job 1: ray records of the level
     const uint4 *kdq;          // job 1: (ray index, root-box entry distance, exit distance, -)
@@ -239,20 +254,14 @@ struct WalkJob {
     uint32_t *shadow;          // job 0: shadow bits of the level the shadow rays belong to
     unsigned long long *best;  // job 1: closest mesh hit keys of the level
     LevelCounters *cnt;        // counters of the job's level
-    uint2 *recs;               // (ray reference, leaf face count << 27 | first slot in S.ltris)
-    uint32_t rec_cap, q_cap;
-    uint32_t enabled, pad;
+    uint32_t q_cap;
+    uint32_t enabled;
 };
 struct WalkArgs {
     SceneDev S;
     WalkJob job[2];
 };
 
-#if defined(RT_DBG_NO_EMIT)
-#define LEAF_EMIT_COND && false
-#else
-#define LEAF_EMIT_COND
-#endif
 #ifndef RT_REFILL_MIN_IDLE
 #define RT_REFILL_MIN_IDLE 24
 #endif
@@ -269,30 +278,86 @@ constexpr int REFILL_MIN_IDLE = RT_REFILL_MIN_IDLE;   // refill once this many l
 // a refill hands out up to one ray per lane from a single reservation, so a chunk must cover a whole wave; a
 // smaller chunk would let the wave's cursor run past its reservation and the wave would never see the queue end
 static_assert(RT_REFILL_CHUNK >= 64, "REFILL_CHUNK must be at least the wave size");
-constexpr int REFILL_CHUNK = RT_REFILL_CHUNK;                    // rays a wave reserves from the global queue per atomic
-#ifndef RT_REC_CHUNK
-#define RT_REC_CHUNK 512
-#endif
-constexpr int REC_CHUNK = RT_REC_CHUNK;                      // records a wave reserves per atomic
+constexpr int REFILL_CHUNK = RT_REFILL_CHUNK;        // rays a wave reserves from the global queue per atomic
 constexpr int SHORT_STACK = RT_SHORT_STACK;          // power of two
 constexpr int MAIL_SLOTS = 32;                       // stretches that change hands in one exchange of a wave
-constexpr uint32_t REC_FILLER = 0u;   // a record's second word is count << 27 | first slot; count 0 = filler
+// leaf records waiting for their triangle tests: lane << 26 | (faces - 1) << 24 | first slot in S.ltris.
+// The ring never holds more than 63 records when a round of the walk starts, and a round adds at most 64.
+constexpr int TEST_RING = 128;
+constexpr uint32_t RING_SLOT_BITS = 24;              // the leaf-ordered triangle table may hold 2^24 slots
+#ifndef RT_TEST_MIN_DRY
+#define RT_TEST_MIN_DRY 64
+#endif
+constexpr uint32_t TEST_MIN_DRY = RT_TEST_MIN_DRY;   // records that trigger a test round once the global queue is dry
+
+// wave-uniform values are passed through readfirstlane so that they live in scalar registers and
+// conditions on them compile to scalar branches instead of lane-mask arithmetic
+#define UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+// 32-bit population count of a wave mask (a 64-bit count would drag 64-bit compares, which have no scalar form)
+#define COUNT_OF(mask) ((uint32_t)__builtin_popcount((uint32_t)(mask)) + (uint32_t)__builtin_popcount((uint32_t)((mask) >> 32)))
+// rank of this lane among the set bits of a wave mask
+#define RANK_IN(mask) __builtin_amdgcn_mbcnt_hi((uint32_t)((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mask), 0u))
+
+// One round of triangle tests: lanes 0 .. n-1 take the n oldest records of the ring. Every lane of the wave must
+// call it (the permutes read the registers of lanes that test nothing themselves). Returns true in the lanes whose
+// OWN shadow ray was found occluded in this round.
+template <bool ANY>
+__device__ __forceinline__ bool test_round(const SceneDev &S, const WalkJob &J, const uint32_t *ring, uint32_t *hit_flag,
+                                           uint32_t head, uint32_t n, uint32_t lane, float ox, float oy, float oz, float dx,
+                                           float dy, float dz, uint32_t ref) {
+    const bool act = lane < n;
+    const uint32_t rec = act ? ring[(head + lane) & (uint32_t)(TEST_RING - 1)] : 0u;
+    const int src = (int)(rec >> 26);
+    const uint32_t first = rec & ((1u << RING_SLOT_BITS) - 1u), count = ((rec >> RING_SLOT_BITS) & 3u) + 1u;
+    // the first triangle is requested before the permutes, which then run under its latency
+    const TriDev *T = S.ltris + first;
+    const V3 v0 = ld3(T->v0), e1 = ld3(T->e1), e2 = ld3(T->e2);
+    const V3 ro = v3(__shfl(ox, src), __shfl(oy, src), __shfl(oz, src));
+    const V3 rd = v3(__shfl(dx, src), __shfl(dy, src), __shfl(dz, src));
+    const uint32_t rref = (uint32_t)__shfl((int)ref, src);
+    if (act) {
+        unsigned long long key = ~0ull;
+        float t;
+        if (hit_tri_regs(v0, e1, e2, S.tri_eps, ro, rd, t)) {
+            // t >= 0 here, so the float bits order like the values; -0 is folded onto +0
+            key = (unsigned long long)((t == 0.0f) ? 0u : __float_as_uint(t)) << 32;
+        }
+        for (uint32_t k = 1; k < count && !(ANY && key != ~0ull); k++) {
+            if (hit_tri(T[k], S.tri_eps, ro, rd, t)) {
+                const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);
+                const unsigned long long kk = ((unsigned long long)tb << 32) | (unsigned long long)k;
+                key = kk < key ? kk : key;
+            }
+        }
+        if (key != ~0ull) {   // few records hit: the rest of the key is made only here
+            if (ANY) {
+                const uint32_t id = J.shq_id[rref];
+                atomicOr(&J.shadow[id >> 5], 1u << (id & 31u));
+                hit_flag[src] = 1u;
+            } else {
+                // low word: visit rank of this leaf for this ray (see path_code), then the face's position in the leaf
+                atomicMin(&J.best[rref], key | (unsigned long long)((T->code ^ near_upper_levels(rd)) << 2));
+            }
+        }
+    }
+    bool mine = false;
+    if (ANY) {
+        __syncthreads();   // one wave per workgroup: orders the flag writes before the reads
+        mine = hit_flag[lane] != 0u;
+        if (mine) hit_flag[lane] = 0u;
+        __syncthreads();
+    }
+    return mine;
+}
 
 template <bool ANY>
-__device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, uint2 *stack, uint4 *mail, const uint32_t lane) {
+__device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, uint2 *stack, uint4 *mail, uint32_t *ring,
+                                         uint32_t *hit_flag, const uint32_t lane) {
     const KdNodeDev *__restrict__ nodes = S.nodes;
     const uint32_t total = ANY ? min(J.cnt->shq_count, J.q_cap) : J.cnt->kdq_count;
     uint32_t *head = ANY ? &J.cnt->shq_head : &J.cnt->kdq_head;
-    uint32_t *rec_count = &J.cnt->rec_count[ANY ? 1 : 0];
     const KdNodeDev root = nodes[0];
 
-    // wave-uniform values are passed through readfirstlane so that they live in scalar registers and
-    // conditions on them compile to scalar branches instead of lane-mask arithmetic
-#define UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-    // rank of this lane among the set bits of a wave mask
-    // 32-bit population count of a wave mask (a 64-bit count would drag 64-bit compares, which have no scalar form)
-#define COUNT_OF(mask) ((uint32_t)__builtin_popcount((uint32_t)(mask)) + (uint32_t)__builtin_popcount((uint32_t)((mask) >> 32)))
-#define RANK_IN(mask) __builtin_amdgcn_mbcnt_hi((uint32_t)((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mask), 0u))
     // wave-uniform: the global queue may still hold rays for this wave. There are ceil(total / chunk) chunks, so at
     // most that many waves can ever get one: the waves beyond that number skip the job without touching the cursor
     uint32_t more = blockIdx.x < (total + (uint32_t)REFILL_CHUNK - 1u) / (uint32_t)REFILL_CHUNK ? 1u : 0u;
@@ -304,15 +369,32 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
     float split = 0.0f;
     int32_t sp_top = 0, sp_lo = 0;           // ring stack: entries sp_lo .. sp_top-1 are valid (at most SHORT_STACK)
     uint32_t chunk_pos = 0, chunk_end = 0;   // wave-uniform: rays reserved from the global queue
-    uint32_t rec_pos = 0, rec_end = 0;       // wave-uniform: record slots reserved in A.recs
+    uint32_t ring_head = 0, ring_tail = 0;   // wave-uniform: records ring_head .. ring_tail-1 wait for their tests (counted on, never wrapped)
+    uint32_t my_last = 0;                    // ring position just behind this lane's newest record
+    uint32_t n_records = 0;                  // wave-uniform: records tested (statistics)
 #ifdef RT_WALK_STATS
     unsigned long long st_iters = 0, st_visits = 0;
     const unsigned long long st_begin = wall_clock64();
 #endif
 
     for (;;) {
-        // ---- refill: while the global queue has rays, as soon as enough lanes are free
-        const unsigned long long idle = __builtin_amdgcn_ballot_w64(info == 0u);
+        // ---- triangle tests: a full round as soon as 64 records wait; what is left when no lane walks any more
+        {
+            const uint32_t waiting = UNIFORM(ring_tail - ring_head);
+            if (waiting != 0u) {
+                const bool nobody_walks = __builtin_amdgcn_ballot_w64(info != 0u) == 0ull;
+                if (waiting >= (UNIFORM(more) ? (uint32_t)WAVE : TEST_MIN_DRY) || nobody_walks) {
+                    const uint32_t n = min(waiting, (uint32_t)WAVE);
+                    const bool mine = test_round<ANY>(S, J, ring, hit_flag, ring_head, n, lane, ox, oy, oz, dx, dy, dz, ref);
+                    ring_head = UNIFORM(ring_head + n);
+                    n_records += n;
+                    if (ANY && mine) info = 0u;   // occluded: whatever else lies along the ray cannot change the bit
+                }
+            }
+        }
+        // ---- refill: while the global queue has rays, as soon as enough lanes are free. A lane is free when its ray
+        //      is finished AND none of its records is still waiting in the ring (those name its ray registers)
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(info == 0u && (int32_t)(my_last - ring_head) <= 0);
         const uint32_t n_idle = COUNT_OF(idle);
         if (n_idle >= (uint32_t)REFILL_MIN_IDLE) {
             if (!UNIFORM(more)) {
@@ -322,10 +404,12 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
                 //      lane hands the OLDEST entry of its stack - the subtree that covers the last stretch of its ray -
                 //      to an idle lane and ends its own ray where that stretch begins. Every entry a lane pushes is
                 //      popped and walked sooner or later (a walk only ends early on a NaN plane distance, which needs
-                //      a zero direction component: such rays do not give), so the same leaves are visited; only who
-                //      visits them changes, and the order of the triangle tests does not matter (see k_tri_test).
+                //      a zero direction component: such rays do not give; and on a shadow ray found occluded, where
+                //      nothing that is skipped matters), so the same leaves are visited; only who visits them changes,
+                //      and the order of the triangle tests does not matter.
                 //      If the ring had dropped entries, the taker inherits the old end of the ray and restarts at the
                 //      root after its stretch, exactly as the giver would have.
+                const bool is_idle = info == 0u && (int32_t)(my_last - ring_head) <= 0;
                 const bool can_give = info != 0u && sp_top != sp_lo && dx != 0.0f && dy != 0.0f && dz != 0.0f &&
                                       dx == dx && dy == dy && dz == dz;
                 const unsigned long long givers = __builtin_amdgcn_ballot_w64(can_give);
@@ -346,7 +430,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
                     }
                     __syncthreads();   // one wave per workgroup: orders the mailbox writes before the reads
                     const uint32_t taker = RANK_IN(idle);
-                    if (info == 0u && taker < min(COUNT_OF(givers), (uint32_t)MAIL_SLOTS)) {
+                    if (is_idle && taker < min(COUNT_OF(givers), (uint32_t)MAIL_SLOTS)) {
                         const uint4 m0 = mail[taker], m1 = mail[MAIL_SLOTS + taker], m2 = mail[2 * MAIL_SLOTS + taker];
                         ref = m0.w;
                         maxDist = __uint_as_float(m1.x);
@@ -365,6 +449,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
                 }
 #endif
             } else {
+                const bool is_idle = info == 0u && (int32_t)(my_last - ring_head) <= 0;
                 const uint32_t rank = RANK_IN(idle);
                 const uint32_t left = chunk_end - chunk_pos;   // rays of the wave's own chunk not handed out yet
                 uint32_t q = 0xffffffffu;
@@ -399,7 +484,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
                         last_chunk = base + (uint32_t)REFILL_CHUNK >= total ? 1u : 0u;
                     }
                 }
-                if (info == 0u && q != 0xffffffffu) {
+                if (is_idle && q != 0xffffffffu) {
                     if (ANY) {
                         ref = q;
                         const float4 fo = J.rays[2 * (size_t)q], fd = J.rays[2 * (size_t)q + 1];
@@ -442,18 +527,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
         // internal node: classify the children and pick the side(s) the ray interval touches
         const uint32_t a = (info >> 28) & 3u;
         const float o = a == 0u ? ox : (a == 1u ? oy : oz), d = a == 0u ? dx : (a == 1u ? dy : dz);
-#ifdef RT_DBG_APPROX_DIV
-        const float t = (split - o) * __builtin_amdgcn_rcpf(d);   // timing experiment only: not the reference's arithmetic
-#else
         const float t = (split - o) / d;
-#endif
-#ifdef RT_DBG_EXTRA_VALU
-        {   // timing experiment only: dead full-rate vector instructions
-            uint32_t dead = info;
-            for (int xd = 0; xd < RT_DBG_EXTRA_VALU; xd++) asm volatile("v_add_u32 %0, %0, %0" : "+v"(dead));
-            asm volatile("" : : "v"(dead));
-        }
-#endif
         const uint32_t child = info & 0x0fffffffu;
         const uint32_t neg = d <= 0.0f ? 1u : 0u;
         const uint32_t nearc = child + neg, farc = child + 1u - neg;
@@ -461,10 +535,10 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
         const bool both = is_int && !ge && !le;
         uint32_t next = (le && !ge) ? farc : nearc;
         if (both) stack[((uint32_t)sp_top & (SHORT_STACK - 1)) * WAVE] = make_uint2(farc, __float_as_uint(tmax));
-        // leaf (or empty leaf): list it (below), then go on with the next cell of the ray
-        const bool is_listed = info >= 0xc0000000u LEAF_EMIT_COND;
+        // leaf with faces: note it (below), then go on with the next cell of the ray
+        const bool is_listed = info >= 0xc0000000u;
         const unsigned long long listed = __builtin_amdgcn_ballot_w64(is_listed);
-        const uint32_t leaf_info = info & 0x3fffffffu;
+        const uint32_t leaf_info = info;
         sp_top += both ? 1 : (pop ? -1 : 0);                  // a push and a pop never meet in one action
         sp_lo = max(sp_lo, sp_top - SHORT_STACK);             // a push onto a full ring drops the oldest entry
         tmin = cont ? tmax : tmin;
@@ -477,27 +551,18 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
             split = n.split;
         }
 
-        // ---- list the leaves just visited: one record (ray, leaf's slot range) per non-empty leaf, in no
-        //      particular order (k_tri_test needs none)
+        // ---- the leaves just entered: one record per non-empty leaf into the wave's ring
         if (listed) {
-            const uint32_t tot = COUNT_OF(listed);
-            if (rec_end - rec_pos < tot) {
-                for (uint32_t p = rec_pos + lane; p < rec_end; p += WAVE) J.recs[p] = make_uint2(0u, REC_FILLER);
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(rec_count, (uint32_t)REC_CHUNK);
-                base = UNIFORM(base);
-                rec_pos = base;
-                // past the capacity nothing is written; the host sees rec_count > capacity and repeats
-                // the level with a larger buffer
-                rec_end = (base + (uint32_t)REC_CHUNK <= J.rec_cap) ? base + (uint32_t)REC_CHUNK : base;
+            if (is_listed) {
+                const uint32_t pos = ring_tail + RANK_IN(listed);
+                ring[pos & (uint32_t)(TEST_RING - 1)] = (lane << 26) | ((((leaf_info >> LEAF_COUNT_SHIFT) & 7u) - 1u) << RING_SLOT_BITS) |
+                                                         (leaf_info & ((1u << RING_SLOT_BITS) - 1u));
+                my_last = pos + 1u;
             }
-            if (rec_end - rec_pos >= tot) {
-                if (is_listed) J.recs[rec_pos + RANK_IN(listed)] = make_uint2(ref, leaf_info);
-                rec_pos += tot;
-            }
+            ring_tail = UNIFORM(ring_tail + COUNT_OF(listed));
         }
     }
-    for (uint32_t p = rec_pos + lane; p < rec_end; p += WAVE) J.recs[p] = make_uint2(0u, REC_FILLER);
+    if (lane == 0 && n_records) atomicAdd(&J.cnt->rec_count[ANY ? 1 : 0], n_records);
 #ifdef RT_WALK_STATS
     if (lane == 0) {
         atomicAdd(&J.cnt->walk_iters[ANY ? 1 : 0], st_iters);
@@ -508,78 +573,21 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
         atomicAdd(&J.cnt->walk_tsum[ANY ? 1 : 0], st_end - st_begin);
     }
 #endif
+}
 #undef RANK_IN
 #undef COUNT_OF
 #undef UNIFORM
-}
 
 __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
     __shared__ uint2 s_stack[SHORT_STACK * WAVE];
     __shared__ uint4 s_mail[3 * MAIL_SLOTS];      // stretches handed from walking lanes to idle ones
+    __shared__ uint32_t s_ring[TEST_RING];        // leaf records waiting for their triangle tests
+    __shared__ uint32_t s_hit[WAVE];              // shadow job: lane l's ray was found occluded
     const uint32_t lane = threadIdx.x;
-    if (A.job[0].enabled) walk_job<true>(A.S, A.job[0], s_stack + lane, s_mail, lane);
-    if (A.job[1].enabled) walk_job<false>(A.S, A.job[1], s_stack + lane, s_mail, lane);
-}
-
-// ---- triangle tests over the records of a walk -------------------------------------------------------------
-// Closest hit: the shader tests a leaf's faces in order and keeps a hit only if `hitInfo.t < tMin`
-// (js/8-kd_tree.js:948-949), i.e. among equal distances the face met FIRST wins. The 64-bit key
-// (t bits, visit rank of the leaf for this ray, face position in the leaf) ordered by an atomic min reproduces
-// that without any assumption on the order in which the records were written; the key also names the winner:
-// rank ^ near_upper_levels(direction) is the leaf's path code, SceneDev::path_slot maps it to the leaf's slots.
-template <bool ANY>
-__device__ __forceinline__ void test_job(const SceneDev &S, const WalkJob &J) {
-    const uint32_t n_rec = min(J.cnt->rec_count[ANY ? 1 : 0], J.rec_cap);
-    const uint32_t stride = gridDim.x * 256;
-    uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_rec) return;
-    uint2 rec = J.recs[r];
-    for (;;) {
-        // the next record is fetched before this one is worked on, and this one's ray and first triangle before the
-        // occlusion check: the loads of a lane then overlap instead of queueing behind each other (a filler names
-        // ray 0 and slot 0, both valid addresses)
-        const uint32_t rn = r + stride;
-        const uint2 next = J.recs[rn < n_rec ? rn : r];
-        const uint32_t count = rec.y >> LEAF_COUNT_SHIFT, first = rec.y & LEAF_SLOT_MASK;
-        V3 ro, rd;
-        load_ray(J.rays, rec.x, ro, rd);
-        const TriDev *T = S.ltris + first;
-        const V3 v0 = ld3(T->v0), e1 = ld3(T->e1), e2 = ld3(T->e2);
-        uint32_t id = 0;
-        bool skip = count == 0u;
-        if (ANY) {
-            id = J.shq_id[rec.x];
-            skip = skip || (J.shadow[id >> 5] & (1u << (id & 31u))) != 0u;   // already known to be occluded
-        }
-        if (!skip) {
-            unsigned long long key = ~0ull;
-            float t;
-            if (hit_tri_regs(v0, e1, e2, S.tri_eps, ro, rd, t)) {
-                // t >= 0 here, so the float bits order like the values; -0 is folded onto +0
-                key = (unsigned long long)((t == 0.0f) ? 0u : __float_as_uint(t)) << 32;
-            }
-            for (uint32_t k = 1; k < count && !(ANY && key != ~0ull); k++) {
-                if (hit_tri(T[k], S.tri_eps, ro, rd, t)) {
-                    const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);
-                    const unsigned long long kk = ((unsigned long long)tb << 32) | (unsigned long long)k;
-                    key = kk < key ? kk : key;
-                }
-            }
-            if (key != ~0ull) {   // few records hit: the rest of the key is made only here
-                if (ANY) atomicOr(&J.shadow[id >> 5], 1u << (id & 31u));
-                // low word: visit rank of this leaf for this ray (see path_code), then the face's position in the leaf
-                else atomicMin(&J.best[rec.x], key | (unsigned long long)((T->code ^ near_upper_levels(rd)) << 2));
-            }
-        }
-        if (rn >= n_rec) break;
-        rec = next;
-        r = rn;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_tri_test(WalkArgs A) {
-    if (A.job[0].enabled) test_job<true>(A.S, A.job[0]);
-    if (A.job[1].enabled) test_job<false>(A.S, A.job[1]);
+    s_hit[lane] = 0u;
+    __syncthreads();
+    if (A.job[0].enabled) walk_job<true>(A.S, A.job[0], s_stack + lane, s_mail, s_ring, s_hit, lane);
+    if (A.job[1].enabled) walk_job<false>(A.S, A.job[1], s_stack + lane, s_mail, s_ring, s_hit, lane);
 }
 
 // (path code, first slot) of every non-empty leaf -> SceneDev::path_slot

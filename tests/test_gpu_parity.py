@@ -364,7 +364,6 @@ def test_buffers_too_small_for_the_first_frame_are_grown_and_the_frame_repeated(
     rt = abi.RayTracerHIP(flat.cfg)
     rt.setScene(flat)
     rt.setOption("first_level_rays", 256)
-    rt.setOption("first_records", 512)
     rt.traceBegin()
     assert rt.traceEnd() is True
     assert np.array_equal(rt.readRGBA8(), want.readRGBA8())
@@ -374,24 +373,6 @@ def test_buffers_too_small_for_the_first_frame_are_grown_and_the_frame_repeated(
     rt.traceBegin()
     assert rt.traceEnd() is False
     assert np.array_equal(rt.readRGBA8(), want.readRGBA8())
-
-
-def test_record_buffer_that_is_not_a_whole_number_of_chunks():
-    """A walking wave writes leaf records in chunks of 512 and skips a chunk that would cross the end of the buffer. With a
-    capacity that is not a multiple of 512 the tail must count as not there: the triangle tests must not read it (the
-    buffers are poisoned with 0xff, so a record read from the tail would name ray 0xffffffff), the overflow must be
-    noticed, and the repeated frame must be exact."""
-    flat = make_flat("bun_zipper_res4.ply", 331, 203, depth=4, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
-    want = render_hip(flat)
-    rt = abi.RayTracerHIP(flat.cfg)
-    rt.setScene(flat)
-    rt.setOption("poison_records", 1)
-    rt.setOption("first_records", 1000)
-    rt.traceBegin()
-    assert rt.traceEnd() is True
-    assert np.array_equal(rt.readRGBA8(), want.readRGBA8())
-    assert np.array_equal(rt.readHitIds(), want.readHitIds())
-    assert rt.stats().rays_total == want.stats().rays_total and rt.stats().shadow_rays == want.stats().shadow_rays
 
 
 def test_pipelined_job_repeats_the_exchange_of_a_retraced_frame():
@@ -409,7 +390,6 @@ def test_pipelined_job_repeats_the_exchange_of_a_retraced_frame():
         rt = abi.RayTracerHIP(flat.cfg)
         rt.setScene(flat)
         rt.setOption("first_level_rays", 256)
-        rt.setOption("first_records", 512)
         rts.append(rt)
     job = multi_gpu.PipelinedFrameJob(rts, multi_gpu.Comm(0, 1, 0, backend=None, device="cuda:0"))
     job.step()

@@ -88,12 +88,18 @@ for k in sorted(acc, key=lambda k: -acc[k].get("SQ_BUSY_CYCLES", 0)):
         cycles = g("GRBM_GUI_ACTIVE") / 8.0
         d["valu_issue_frac"] = g("SQ_INSTS_VALU") / (cycles * 256.0)
         d["salu_per_cycle_cu"] = g("SQ_INSTS_SALU") / (cycles * 256.0)
+        # per launch, so that a live duration can be priced against the same instruction count
+        d["valu_insts_per_launch"] = g("SQ_INSTS_VALU") / max(cnt[k]["SQ_INSTS_VALU"], 1)
+        d["gui_cycles_per_launch"] = cycles / max(cnt[k]["GRBM_GUI_ACTIVE"], 1)
+        if d.get("avg_us"):
+            d["clock_mhz_profiled"] = d["gui_cycles_per_launch"] / d["avg_us"]
         print("   -> vector instructions issued per cycle and CU = %.3f of 1.0 (scalar: %.3f)" % (d["valu_issue_frac"], d["salu_per_cycle_cu"]))
     if g("SQ_WAVES") and g("SQ_INSTS_VALU"):
         d["insts_per_wave"] = {n: g("SQ_INSTS_" + n) / g("SQ_WAVES") for n in ("VALU", "SALU", "VMEM_RD", "LDS", "SMEM")}
     if g("TCC_HIT_sum") + g("TCC_MISS_sum"):
         d["l2_hit"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
-        print("   -> L2 hit rate = %.4f" % d["l2_hit"])
+        d["tcc_req_per_launch"] = g("TCC_REQ_sum") / max(cnt[k]["TCC_REQ_sum"], 1)
+        print("   -> L2 hit rate = %.4f, %.1f M requests per launch" % (d["l2_hit"], d["tcc_req_per_launch"] / 1e6))
     if g("TCP_TOTAL_CACHE_ACCESSES_sum"):
         d["l1_hit"] = 1.0 - g("TCP_TCC_READ_REQ_sum") / g("TCP_TOTAL_CACHE_ACCESSES_sum")
         print("   -> vector L1 hit rate (1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES) = %.4f" % d["l1_hit"])
