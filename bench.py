@@ -8,7 +8,7 @@ One step = one whole frame of the hot path with the scene already resident in HB
 value = rays traced by all ranks (valid ray-tree nodes: primary + reflected + refracted; shadow rays are
 reported separately) / max-over-ranks wall time of the K timed steps.
 
-Launch: python bench.py --gpus 1   |   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+Launch: python bench.py --gpus N (starts its N ranks itself)   |   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
 """
 import argparse
 import ctypes as C
@@ -30,6 +30,10 @@ from ray_tracer_amd import abi, multi_gpu, scene  # noqa: E402
 MESH_MATERIAL = (0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9)   # ka kd ks ke kReflect kRefract ior: the mesh reflects and transmits
 HBM_PEAK_GBS = 8000.0
 FP32_PEAK_TFLOPS = 157.3
+VALU_ISSUE_PEAK = 2.0        # wave64 vector instructions per cycle per CU: four SIMD-32 units, two cycles each
+L2_PEAK_BS = 34.5e12         # aggregate L2 bandwidth
+L2_LINE_BYTES = 128.0
+PMC_DIGEST = "r02_pmc_digest.json"   # written by tools/prof.sh + tools/prof_summary.py for the committed kernels
 
 
 TEAPOT = (os.path.join(ROOT, "assets", "models", "teapot.obj"), 60.0, (50.0, 75.0, 10.0))   # file, scale, translation (checkpoint 6 places it so, js/6-transmission.js:2010-2014)
@@ -42,6 +46,42 @@ def build_workload(model="bun_zipper.ply", teapot=True, time=0.0):
                              extra_mesh=TEAPOT if teapot else None)
     scene.animate_light(sc, time)
     return sc
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: starts the N ranks as child processes of this one (which never
+    touches the GPU), forwards rank 0's JSON line and returns the first non-zero exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    status = 0
+    alive = set(range(n))
+    out0 = b""
+    while alive:
+        for r in sorted(alive):
+            try:
+                if r == 0:
+                    o, _ = procs[0].communicate(timeout=0.5)
+                    out0 += o or b""
+                else:
+                    procs[r].wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            alive.discard(r)
+            if procs[r].returncode != 0 and status == 0:
+                status = procs[r].returncode
+                for q in alive:            # the others would wait for the lost rank in their next collective
+                    procs[q].terminate()
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return status
 
 
 def main():
@@ -68,16 +108,26 @@ def main():
                     help="tiles: every frame is split over the GPUs (all-reduce + gather per frame); frames: step k is traced whole by rank k mod N, no exchange")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (rehearsal on a one-GPU box); default LOCAL_RANK")
+    ap.add_argument("--spawn-check", action="store_true", help="only start the ranks and add up their numbers over a gloo group (no GPU needed): checks the single-command launch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))     # one process per GPU, started from here
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                             % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if args.spawn_check:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "rank_sum": int(t[0])}))
+        dist.destroy_process_group()
+        return
 
     import torch
     if args.device is not None:
@@ -240,56 +290,79 @@ def main():
             "sample": "same frame, every %d-th pixel in x and y (%d rays, %.1f s), oracle/trace_oracle.c with OpenMP"
                       % (args.cpu_step, cn.rays, cpu_s),
         }
-        # ---- roofline of the dominant kernel: the k-d walk of the shadow rays (k_kd_walk<true>), one launch
-        # per ray-tree level. Algorithmic bytes = what the REFERENCE traversal fetches for the same rays
-        # (8 B per descent step + 16 B per leaf visit; the triangle fetches belong to k_tri_test), counted by
-        # the instrumented oracle on the sample and scaled to the frame. Duration = HIP events on the library's
-        # stream around every launch (rt_stats.level_stage_ms), averaged over the launches of the timed steps.
+        # ---- roofline of the dominant kernel, k_kd_walk (one launch per pipeline step: the closest-hit rays of a
+        # ray-tree level and the shadow rays of the level before it, triangle tests included).
+        # The scene is cache-resident and nothing contracts, so neither HBM nor MFMA bounds this kernel; the roof it
+        # sits under is VECTOR INSTRUCTION ISSUE: a CU has four SIMD-32 units, a wave64 vector instruction takes one of
+        # them for 2 cycles, so a CU issues at most 2 per cycle. achieved = vector instructions of one launch (PMC
+        # SQ_INSTS_VALU of the committed profile of this binary and workload; the count does not depend on timing)
+        # / (launch duration measured here with HIP events on the library's stream x shader clock of that profile
+        # (GRBM_GUI_ACTIVE / duration) x number of CUs). Beside it: the L2 and HBM fractions from the same profile's
+        # request counts over the live duration, and the reference-algorithm bytes and flops of the same rays (what the
+        # reference's restart traversal would fetch: 8 B per descent step, 16 B per leaf visit, 48 B per triangle test;
+        # counted by the instrumented oracle over the same frame) - a workload figure, not a bandwidth the kernel moves.
         tile_world = 1 if by_frames else world
         scale = float(args.cpu_step ** 2) / tile_world
         D = args.depth
         n_steps = D + 1
-        # per pipeline stage: reference-algorithm bytes and flops of everything that stage does in one frame
-        per_stage_bytes = np.zeros(5)
-        per_stage_flops = np.zeros(5)
+        names = out["stage_names"]
+        per_stage_bytes = np.zeros(4)
+        per_stage_flops = np.zeros(4)
         for lv in range(D):
             per_stage_bytes += np.array([128.0 * cn.prim_tests[lv],
-                                         8.0 * (cn.kd_steps[lv] + cn.sh_steps[lv]) + 16.0 * (cn.kd_leaf_visits[lv] + cn.sh_leaf_visits[lv]),
-                                         48.0 * (cn.kd_tri_tests[lv] + cn.sh_tri_tests[lv]), 0.0, 128.0 * cn.sh_prim_tests[lv]])
-            per_stage_flops += np.array([60.0 * cn.prim_tests[lv], 14.0 * (cn.kd_steps[lv] + cn.sh_steps[lv]),
-                                         45.0 * (cn.kd_tri_tests[lv] + cn.sh_tri_tests[lv]), 0.0, 60.0 * cn.sh_prim_tests[lv]])
+                                         8.0 * (cn.kd_steps[lv] + cn.sh_steps[lv]) + 16.0 * (cn.kd_leaf_visits[lv] + cn.sh_leaf_visits[lv])
+                                         + 48.0 * (cn.kd_tri_tests[lv] + cn.sh_tri_tests[lv]), 0.0, 128.0 * cn.sh_prim_tests[lv]])
+            per_stage_flops += np.array([60.0 * cn.prim_tests[lv], 14.0 * (cn.kd_steps[lv] + cn.sh_steps[lv])
+                                         + 45.0 * (cn.kd_tri_tests[lv] + cn.sh_tri_tests[lv]), 0.0, 60.0 * cn.sh_prim_tests[lv]])
         per_stage_bytes *= scale
         per_stage_flops *= scale
-        tot_ms = stage_ms[:n_steps, :5].sum(axis=0)
-        launches = np.array([D, n_steps, n_steps, D, D], dtype=float)   # per frame: levels have a closest-hit half (steps 0..D-1) and a shadow half (steps 1..D)
-        dom = int(np.argmax(tot_ms))
+        tot_ms = stage_ms[:n_steps, :4].sum(axis=0)
+        launches = np.array([D, n_steps, D, D], dtype=float)   # per frame: a level has a closest-hit half (steps 0..D-1) and a shadow half (steps 1..D)
         digest = {}
-        dpath = os.path.join(ROOT, "profiles", "r01_pmc_digest.json")
+        dpath = os.path.join(ROOT, "profiles", PMC_DIGEST)
         if os.path.exists(dpath):
             with open(dpath) as f:
                 digest = json.load(f)
-        prof_name = dict(enumerate(out["stage_names"]))
+        n_cus = torch.cuda.get_device_properties(local).multi_processor_count
         table = []
-        for k in range(5):
-            if launches[k] == 0:
-                continue
+        for k in range(4):
             dur_s = tot_ms[k] / launches[k] * 1e-3
-            b = per_stage_bytes[k] / launches[k]
-            table.append({"kernel": prof_name[k], "launches_per_frame": int(launches[k]), "avg_launch_ms": tot_ms[k] / launches[k],
-                          "algorithmic_bytes_per_launch": b, "achieved_GBs": b / dur_s / 1e9,
-                          "valu_tflops": per_stage_flops[k] / launches[k] / dur_s / 1e12,
-                          "traffic": digest.get(prof_name[k], {}).get("hbm_bytes_per_launch") if world == 1 else None,
-                          "valu_issue_frac_profiled": digest.get(prof_name[k], {}).get("valu_issue_frac"),
-                          "l2_hit_profiled": digest.get(prof_name[k], {}).get("l2_hit")})
-        d = next(t for t in table if t["kernel"] == prof_name[dom])
+            g = digest.get(names[k], {})
+            row = {"kernel": names[k], "launches_per_frame": int(launches[k]), "avg_launch_ms": tot_ms[k] / launches[k],
+                   "reference_algorithm_bytes_per_launch": per_stage_bytes[k] / launches[k],
+                   "reference_algorithm_tflops": per_stage_flops[k] / launches[k] / dur_s / 1e12,
+                   "valu_issue": None, "l2_frac": None, "hbm_frac": None, "traffic": None,
+                   "valu_issue_frac_profiled": None, "lanes_per_valu_inst_profiled": g.get("valu_lanes_per_inst"),
+                   "l2_hit_profiled": g.get("l2_hit"), "avg_launch_ms_profiled": (g.get("avg_us") or 0.0) / 1e3 or None}
+            if world == 1 and g.get("valu_insts_per_launch") and g.get("clock_mhz_profiled"):
+                cyc = dur_s * g["clock_mhz_profiled"] * 1e6
+                row["valu_issue"] = g["valu_insts_per_launch"] / (cyc * n_cus)
+                row["valu_issue_frac_profiled"] = g["valu_issue_frac"] / VALU_ISSUE_PEAK
+                row["traffic"] = g.get("hbm_bytes_per_launch")
+                if g.get("tcc_req_per_launch"):
+                    row["l2_frac"] = g["tcc_req_per_launch"] * L2_LINE_BYTES / dur_s / L2_PEAK_BS
+                if row["traffic"] is not None:
+                    row["hbm_frac"] = row["traffic"] / dur_s / (HBM_PEAK_GBS * 1e9)
+            table.append(row)
+        d = table[int(np.argmax(tot_ms))]
         out["roofline"] = {
-            "bound": "hbm", "kernel": d["kernel"], "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": d["achieved_GBs"] / HBM_PEAK_GBS, "traffic": d["traffic"],
-            "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "avg_launch_ms": d["avg_launch_ms"],
-            "launches_per_frame": d["launches_per_frame"],
-            "valu_tflops": d["valu_tflops"], "valu_frac": d["valu_tflops"] / FP32_PEAK_TFLOPS,
-            "valu_issue_frac_profiled": d["valu_issue_frac_profiled"], "l2_hit_profiled": d["l2_hit_profiled"],
-            "note": "one k_kd_walk launch per pipeline step walks the closest-hit rays of a ray-tree level together with the shadow rays of the previous one; algorithmic bytes = the reference restart traversal's fetches for the same rays (8 B per descent step, 16 B per leaf visit), counted by the instrumented oracle over the same frame; the kernel keeps a stack where the reference restarts from the root for every cell, so it moves far fewer bytes than that and the figure can exceed the HBM peak; the scene (about 20 MB) stays in L2 / Infinity Cache, so this walk is bound by vector instruction issue (valu_issue_frac_profiled: wave64 vector instructions per cycle and CU, peak 1, from the committed PMC pass) and dependent-gather latency, not by HBM or MFMA; `traffic` is HBM bytes per launch from the committed PMC pass (2*FETCH_SIZE + WRITE_SIZE), mostly the leaf records written",
+            "bound": "valu_issue", "kernel": d["kernel"],
+            "achieved": d["valu_issue"], "peak": VALU_ISSUE_PEAK, "unit": "wave64 vector instructions per cycle per CU",
+            "frac": None if d["valu_issue"] is None else d["valu_issue"] / VALU_ISSUE_PEAK,
+            "traffic": d["traffic"],
+            "l2_frac": d["l2_frac"], "hbm_frac": d["hbm_frac"],
+            "valu_flop_frac": d["reference_algorithm_tflops"] / FP32_PEAK_TFLOPS,
+            "reference_algorithm_bytes_per_launch": d["reference_algorithm_bytes_per_launch"],
+            "reference_algorithm_tflops": d["reference_algorithm_tflops"],
+            "avg_launch_ms": d["avg_launch_ms"], "launches_per_frame": d["launches_per_frame"],
+            "valu_issue_frac_profiled": d["valu_issue_frac_profiled"], "lanes_per_valu_inst_profiled": d["lanes_per_valu_inst_profiled"],
+            "l2_hit_profiled": d["l2_hit_profiled"], "pmc_profile": "profiles/" + PMC_DIGEST,
+            "note": "frac = vector instructions issued per cycle and CU over the CU's peak of 2 (four SIMD-32, two cycles per wave64 instruction); "
+                    "instruction and request counts per launch come from the committed rocprofv3 PMC passes of this binary on this workload, the "
+                    "duration from HIP events in this run; l2_frac = TCC_REQ x 128 B / duration / 34.5 TB/s (an upper bound: a request may "
+                    "carry 64 B); traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch = bytes that left L2 for the fabric, Infinity-Cache hits "
+                    "included, so hbm_frac is an upper bound (the leaf-ordered triangle table of 14 MB does not fit the 4 MB L2 of an XCD "
+                    "and is served by the Infinity Cache); neither HBM nor MFMA bounds this path",
         }
         out["kernels"] = table
         out["algorithmic_frame"] = {k: v * scale * tile_world for k, v in cn.algorithmic(None).items()}

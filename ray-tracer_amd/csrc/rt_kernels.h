@@ -309,35 +309,35 @@ __device__ __forceinline__ bool test_round(const SceneDev &S, const WalkJob &J, 
     const uint32_t rec = act ? ring[(head + lane) & (uint32_t)(TEST_RING - 1)] : 0u;
     const int src = (int)(rec >> 26);
     const uint32_t first = rec & ((1u << RING_SLOT_BITS) - 1u), count = ((rec >> RING_SLOT_BITS) & 3u) + 1u;
-    // the first triangle is requested before the permutes, which then run under its latency
+    // Lanes beyond n (only when the ring is drained with fewer than 64 records) run the same code on slot 0 and
+    // lane 0's ray and drop the result: with no branch around the arithmetic the triangle loads are issued first and
+    // the permutes and the other lanes' work run under their latency
     const TriDev *T = S.ltris + first;
     const V3 v0 = ld3(T->v0), e1 = ld3(T->e1), e2 = ld3(T->e2);
     const V3 ro = v3(__shfl(ox, src), __shfl(oy, src), __shfl(oz, src));
     const V3 rd = v3(__shfl(dx, src), __shfl(dy, src), __shfl(dz, src));
     const uint32_t rref = (uint32_t)__shfl((int)ref, src);
-    if (act) {
-        unsigned long long key = ~0ull;
-        float t;
-        if (hit_tri_regs(v0, e1, e2, S.tri_eps, ro, rd, t)) {
-            // t >= 0 here, so the float bits order like the values; -0 is folded onto +0
-            key = (unsigned long long)((t == 0.0f) ? 0u : __float_as_uint(t)) << 32;
+    unsigned long long key = ~0ull;
+    float t;
+    if (hit_tri_regs(v0, e1, e2, S.tri_eps, ro, rd, t)) {
+        // t >= 0 here, so the float bits order like the values; -0 is folded onto +0
+        key = (unsigned long long)((t == 0.0f) ? 0u : __float_as_uint(t)) << 32;
+    }
+    for (uint32_t k = 1; k < count && !(ANY && key != ~0ull); k++) {
+        if (hit_tri(T[k], S.tri_eps, ro, rd, t)) {
+            const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);
+            const unsigned long long kk = ((unsigned long long)tb << 32) | (unsigned long long)k;
+            key = kk < key ? kk : key;
         }
-        for (uint32_t k = 1; k < count && !(ANY && key != ~0ull); k++) {
-            if (hit_tri(T[k], S.tri_eps, ro, rd, t)) {
-                const uint32_t tb = (t == 0.0f) ? 0u : __float_as_uint(t);
-                const unsigned long long kk = ((unsigned long long)tb << 32) | (unsigned long long)k;
-                key = kk < key ? kk : key;
-            }
-        }
-        if (key != ~0ull) {   // few records hit: the rest of the key is made only here
-            if (ANY) {
-                const uint32_t id = J.shq_id[rref];
-                atomicOr(&J.shadow[id >> 5], 1u << (id & 31u));
-                hit_flag[src] = 1u;
-            } else {
-                // low word: visit rank of this leaf for this ray (see path_code), then the face's position in the leaf
-                atomicMin(&J.best[rref], key | (unsigned long long)((T->code ^ near_upper_levels(rd)) << 2));
-            }
+    }
+    if (act && key != ~0ull) {   // few records hit: the rest of the key is made only here
+        if (ANY) {
+            const uint32_t id = J.shq_id[rref];
+            atomicOr(&J.shadow[id >> 5], 1u << (id & 31u));
+            hit_flag[src] = 1u;
+        } else {
+            // low word: visit rank of this leaf for this ray (see path_code), then the face's position in the leaf
+            atomicMin(&J.best[rref], key | (unsigned long long)((T->code ^ near_upper_levels(rd)) << 2));
         }
     }
     bool mine = false;

@@ -188,3 +188,46 @@ def test_two_hip_shards_equal_one_context():
     for r in results.values():
         assert abs(r["Lbar"] - Lbar) <= 1e-10 * Lbar and np.float32(r["sf"]) == np.float32(sf)
     rt.close()
+
+
+def _run_bench(args, timeout=600):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(_ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks_from_one_command():
+    """`python bench.py --gpus N` with no launcher: the process starts N child ranks itself (it never touches the GPU),
+    forwards rank 0's single JSON line and its exit status. --spawn-check stops after a gloo all-reduce of the rank
+    numbers, so this runs without a GPU."""
+    out = _run_bench(["--gpus", "3", "--spawn-check"], timeout=300)
+    assert out == {"n_gpus": 3, "rank_sum": 6}
+
+
+def test_bench_spawn_reports_a_failing_rank():
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(_ROOT, "bench.py"), "--gpus", "2", "--spawn-check", "--no-such-flag"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_from_one_command():
+    """The whole N = 2 bench path (tiles sharded, luminance all-reduce, tile gather, assemble, present) started by
+    `python bench.py --gpus 2` alone, rehearsed with both ranks on device 0 over gloo."""
+    out = _run_bench(["--gpus", "2", "--backend", "gloo", "--device", "0", "--no-cpu", "--model", "bun_zipper_res4.ply", "--teapot", "0",
+                      "--width", "320", "--height", "240", "--steps", "3", "--warmup", "1"])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
+    one = _run_bench(["--gpus", "1", "--no-cpu", "--model", "bun_zipper_res4.ply", "--teapot", "0",
+                      "--width", "320", "--height", "240", "--steps", "3", "--warmup", "1"])
+    assert one["config"]["rays_per_frame"] == out["config"]["rays_per_frame"]
+    assert one["config"]["shadow_rays_per_frame"] == out["config"]["shadow_rays_per_frame"]
