@@ -243,6 +243,24 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value);
 
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 
+/* ---- for callers that cannot allocate ----------------------------------------------------- */
+/* No counterpart in the reference. The log-luminance reduction of rt_tone_partial_device (js/8-kd_tree.js:2559-2567:
+ * sum of log(EPSILON + L) over the pixels whose alpha byte is not zero, and their count) for callers that must not
+ * allocate device memory: code under HIP graph capture, serving loops, harnesses that forbid hipMalloc. It takes
+ * no context and calls no hipMalloc, hipFree or any other allocating routine: the per-block partial sums live in a
+ * 16 KB array in the library's device image, one copy per GPU, held until the process ends.
+ *   d_rgba8      device memory, n_pixels RGBA8 pixels (any order; what rt_device_shard_rgba8 or rt_device_rgba8 hand out)
+ *   n_pixels     1 .. RT_NOALLOC_MAX_PIXELS, larger inputs are refused
+ *   L_max        rt_config.L_max
+ *   d_sum_count  device memory, two doubles: receives {sum of log luminance, pixel count}, as rt_tone_partial_device yields
+ *   device       the HIP device all three live on; stream: the hipStream_t to queue the two kernels on (NULL = default)
+ * The result is bit-identical to rt_tone_partial's for the same pixels. All calls on one GPU share the array, so two
+ * calls that overlap in time on one GPU (different streams, different threads) race: order them. Returns 0, or -1 with the
+ * reason in rt_noalloc_last_error(). */
+#define RT_NOALLOC_MAX_PIXELS (1ull << 30)
+int rt_luminance_sums_noalloc(const void *d_rgba8, uint64_t n_pixels, float L_max, void *d_sum_count, int32_t device, void *stream);
+const char *rt_noalloc_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,6 +162,8 @@ def lib():
         L.rt_tone_get.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rt_stream.argtypes = [vp, C.POINTER(vp)]
         L.rt_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+        L.rt_luminance_sums_noalloc.argtypes = [vp, C.c_uint64, C.c_float, vp, i32, vp]
+        L.rt_noalloc_last_error.restype = C.c_char_p
         _lib = L
     return _lib
 

@@ -125,6 +125,31 @@ namespace {
 
 constexpr int TONE_BLOCKS = 1024;
 
+// Working memory of rt_luminance_sums_noalloc: per-block partial sums and counts of the two-stage reduction and the two
+// totals. One copy per GPU, held until the process ends; calls that overlap on one GPU would race on it.
+struct ToneScratch {
+    double part_sum[TONE_BLOCKS];
+    unsigned long long part_cnt[TONE_BLOCKS];
+    double out_sum;
+    unsigned long long out_cnt;
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(ToneScratch)];
+constexpr int MAX_SCRATCH_DEVICES = 64;
+ToneScratch *g_scratch_ptr[MAX_SCRATCH_DEVICES] = {};   // device address of `scratch` on every GPU that has asked for it
+
+// `scratch` names a host-side stand-in; the array's address on the CURRENT device comes from the runtime, once per device
+hipError_t scratch_on_current_device(int device, ToneScratch **out) {
+    if (device < 0 || device >= MAX_SCRATCH_DEVICES) return hipErrorInvalidDevice;
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = (ToneScratch *)p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 #define HIPCK(call)                                                                                            \
     do {                                                                                                       \
         hipError_t e_ = (call);                                                                                \
@@ -410,6 +435,10 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     }
     for (auto &ev : ctx->ev_misc)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    {   // set-up for rt_luminance_sums_noalloc on this device, so that its first call there has nothing left to resolve
+        ToneScratch *sp = nullptr;
+        if ((e = scratch_on_current_device(cfg->device, &sp)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
+    }
     FrameGeom &g = ctx->g;
     g.W = cfg->width * cfg->supersampling;
     g.H = cfg->height * cfg->supersampling;
@@ -947,6 +976,31 @@ static int queue_tone_reduction(rt_ctx *ctx) {
                        ctx->d_tone_cnt, ctx->d_tone_pair);
     HIPCK(hipGetLastError());
     HIPCK(hipEventRecord(ctx->ev_misc[1], s));
+    return 0;
+}
+
+static thread_local std::string g_noalloc_error;
+
+const char *rt_noalloc_last_error(void) { return g_noalloc_error.c_str(); }
+
+int rt_luminance_sums_noalloc(const void *d_rgba8, uint64_t n_pixels, float L_max, void *d_sum_count, int32_t device, void *stream) {
+    auto bad = [&](const std::string &m) { g_noalloc_error = "rt_luminance_sums_noalloc: " + m; return -1; };
+    if (!d_rgba8 || !d_sum_count) return bad("null buffer");
+    if (n_pixels == 0) return bad("zero pixels");
+    if (n_pixels > RT_NOALLOC_MAX_PIXELS) return bad("more than RT_NOALLOC_MAX_PIXELS (2^30) pixels");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return bad(std::string("hipSetDevice: ") + hipGetErrorString(e));
+    ToneScratch *sp = nullptr;
+    if ((e = scratch_on_current_device(device, &sp)) != hipSuccess) return bad(std::string("hipGetSymbolAddress: ") + hipGetErrorString(e));
+    // every word of the scratch that the second stage reads is written by the first stage of the same call, so
+    // nothing needs clearing between calls
+    const uint32_t n = (uint32_t)n_pixels;
+    int blocks = (int)std::min<uint32_t>((n + 255) / 256, TONE_BLOCKS);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_tone_partial, dim3(blocks), dim3(256), 0, s, (const uint32_t *)d_rgba8, n, (double)L_max, sp->part_sum, sp->part_cnt);
+    hipLaunchKernelGGL(k_tone_final, dim3(1), dim3(64), 0, s, sp->part_sum, sp->part_cnt, blocks, &sp->out_sum, &sp->out_cnt,
+                       (double *)d_sum_count);
+    if ((e = hipGetLastError()) != hipSuccess) return bad(std::string("launch: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -1,0 +1,45 @@
+"""rt_luminance_sums_noalloc: the luminance reduction for callers that cannot allocate device memory, against
+rt_tone_partial on the same pixels. Two calls in a row, the second on a smaller input (the library's per-GPU working
+array keeps the first call's contents)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import make_flat
+from ray_tracer_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_noalloc_luminance_sums_equal_rt_tone_partial():
+    import torch
+    L = abi.lib()
+    out = torch.zeros(2, dtype=torch.float64, device="cuda:0")       # the caller's output buffer
+    for w, h in ((331, 203), (101, 75)):
+        flat = make_flat("bun_zipper_res4.ply", w, h, depth=2)
+        rt = abi.RayTracerHIP(flat.cfg)
+        rt.setScene(flat)
+        rt.trace()
+        want_sum, want_cnt = rt.tonePartial()
+        p, nb = C.c_void_p(), C.c_size_t()
+        assert L.rt_device_shard_rgba8(rt.ctx, C.byref(p), C.byref(nb)) == 0
+        out.fill_(-1.0)
+        torch.cuda.synchronize()
+        rc = L.rt_luminance_sums_noalloc(p, nb.value // 4, flat.cfg.L_max, C.c_void_p(out.data_ptr()), 0, None)
+        assert rc == 0, L.rt_noalloc_last_error()
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert got[0] == want_sum and got[1] == float(want_cnt) == w * h, (got, want_sum, want_cnt)
+        # the full-frame target works too (here every pixel has alpha 255)
+        p2, nb2 = C.c_void_p(), C.c_size_t()
+        assert L.rt_device_rgba8(rt.ctx, C.byref(p2), C.byref(nb2)) == 0
+        assert L.rt_luminance_sums_noalloc(p2, nb2.value // 4, flat.cfg.L_max, C.c_void_p(out.data_ptr()), 0, None) == 0
+        torch.cuda.synchronize()
+        got2 = out.cpu().numpy()
+        assert got2[1] == w * h and abs(got2[0] - want_sum) <= 1e-12 * abs(want_sum)
+        rt.close()
+    # sizes beyond the stated maximum and null buffers are refused with a message
+    assert L.rt_luminance_sums_noalloc(p, (1 << 30) + 1, 1000.0, C.c_void_p(out.data_ptr()), 0, None) == -1
+    assert b"RT_NOALLOC_MAX_PIXELS" in L.rt_noalloc_last_error()
+    assert L.rt_luminance_sums_noalloc(None, 64, 1000.0, C.c_void_p(out.data_ptr()), 0, None) == -1
