@@ -28,3 +28,7 @@ node $H --script $K8 --model models/bun_zipper.ply --width 3840 --height 2160 --
 node $H --script $K8 --model models/bun_zipper_res4.ply --depth 3 \
      --mesh-material 0.7,0.6,0.7,16,0.3,0.5,0.9 --extra-obj models/teapot.obj --extra-scale 60 --extra-translate 50,75,10 \
      --out $G/k8_res4_teapot_640x480 --full-arrays
+# N3: the mesh picked with a click, grabbed and dragged with the reference's own UI.mouseDown / mouseMove / mouseUp
+# (js/8-kd_tree.js:2718-2792); the arrays and the tree are those of the frame after the drag
+node $H --script $K8 --model models/bun_zipper_res4.ply --depth 3 --mesh-material 0.7,0.6,0.7,16,0.3,0.5,0.9 \
+     --drag 330,40,335,120,330,200 --out $G/k8_res4_drag_640x480

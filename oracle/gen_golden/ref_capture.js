@@ -286,6 +286,15 @@ setImmediate(() => {
         phongBlinnMaterials: cnt(/uniform Phong phongBlinnMaterials\[(\d+)\]/),
         phongCheckeredMaterials: cnt(/uniform PhongCheckered phongCheckeredMaterials\[(\d+)\]/),
         ray_tree_size: cnt(/RAY_TREE_SIZE = int\((\d+)\)/),
+        // the numeric constants as the generated shader text spells them
+        constants: (() => {
+            const o = {};
+            for (const name of ['INFINITY', 'EPSILON', 'SPHERE_EPSILON', 'PLANE_RECT_EPSILON', 'TRIANGLE_EPSILON']) {
+                const m = new RegExp('const float ' + name + ' = (?:float\\()?([-+0-9.eE]+)\\)?;').exec(tracerSrc);
+                o[name] = m ? +m[1] : null;
+            }
+            return o;
+        })(),
         num_faces: cnt(/const int numFaces = (\d+)/),
         closest_tests: (tracerSrc.match(/&& \(hitInfo\.t < tMin\)\) \{\s*hitInfo\.hit = true;\s*hitPoint = rayOrigin \+ rayDir \* hitInfo\.t;\s*tMin = hitInfo\.t;\s*normal = hitInfo\.normal;\s*localHitPoint = hitInfo\.localHitPoint;\s*materialType = \d+;/g) || []).length,
         intersect_order: (tracerSrc.match(/if\(\s*intersect(\w+)\(rayOrigin, rayDir, hitInfo, model\d+, invModel\d+\)\s*&& \(hitInfo\.t < tMin\)/g) || [])

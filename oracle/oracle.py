@@ -33,6 +33,7 @@ def lib():
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib.oracle_tone.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib.oracle_present.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        _lib.oracle_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.oracle_pow.restype = C.c_float
         _lib.oracle_pow.argtypes = [C.c_float, C.c_float]
         _lib.oracle_sizeof_scene.restype = C.c_size_t
@@ -156,6 +157,19 @@ class OracleRenderer:
                            rgb.ctypes.data if rgb is not None else None, rgba.ctypes.data,
                            ids.ctypes.data if ids is not None else None, C.addressof(cn), threads)
         return rgb, rgba, ids, cn
+
+    def probe(self, ro, rd):
+        """One ray-tree node for an arbitrary ray (known-answer tests): dict of the closest hit, the local colour and the
+        two child rays exactly as the pixel loop forms them."""
+        o = np.ascontiguousarray(ro, np.float32)
+        d = np.ascontiguousarray(rd, np.float32)
+        out = np.zeros(31, np.float32)
+        lib().oracle_probe(C.addressof(self.s), o.ctypes.data, d.ctypes.data, out.ctypes.data)
+        return {"hit": bool(out[0]), "id": int(out[1]) if out[0] else -1, "t": float(out[2]), "point": out[3:6].astype(np.float64),
+                "normal": out[6:9].astype(np.float64), "local": out[9:12].astype(np.float64), "colour": out[12:15].astype(np.float64),
+                "kReflect": float(out[15]), "kRefract": float(out[16]), "ior": float(out[17]),
+                "refr_o": out[18:21].astype(np.float64), "refr_d": out[21:24].astype(np.float64),
+                "refl_o": out[24:27].astype(np.float64), "refl_d": out[27:30].astype(np.float64), "lights_blocked": int(out[30])}
 
     def tone(self, rgba):
         a = np.ascontiguousarray(rgba, dtype=np.uint8)

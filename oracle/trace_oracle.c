@@ -506,30 +506,12 @@ static f3 illuminate(const oracle_scene *sc, const HitInfo *h, f3 rd, float *ref
     return add3(F3(0, 0, 0), add3(add3(ambient, specular), diffuse));
 }
 
-typedef struct { int valid; f3 ro, rd, color; float kReflect, kRefract; } TreeNode;
-
-#define MAX_TREE 255
-
-/* One fragment. Returns the colour; *hit_id = id of what the primary ray hit. */
-static f3 shadePixel(const oracle_scene *sc, f3 primaryDir, int32_t *hit_id, oracle_counters *cn) {
-    TreeNode tree[MAX_TREE];
-    int size = (1 << sc->cfg.max_depth) - 1;
-    if (size > MAX_TREE) size = MAX_TREE;
-    memset(tree, 0, sizeof(TreeNode) * (size_t)size);
-    tree[0].valid = 1;
-    tree[0].ro = F3(sc->cam[0], sc->cam[1], sc->cam[2]);
-    tree[0].rd = normalize3(primaryDir);
-    *hit_id = -1;
-    for (int node = 0; node < size; ++node) {
-        if (!tree[node].valid) continue;
-        f3 ro = tree[node].ro, rd = tree[node].rd;
-        int level = 0; for (int n = node + 1; n > 1; n >>= 1) level++;
-        if (level > 7) level = 7;
-        cn->rays++; cn->rays_level[level]++;
-        Closest best; memset(&best, 0, sizeof best);
-        best.tMin = sc->cfg.infinity; best.face = -1;
-        int prim_hit = -1;
-        HitInfo h; memset(&h, 0, sizeof h);
+/* The closest-hit search of one ray-tree node (js/8-kd_tree.js:846-990): analytic primitives in scene order, then the
+ * mesh. Fills h (hit flag) and best; *prim_hit = index of the winning analytic primitive or -1. */
+static void findClosest(const oracle_scene *sc, f3 ro, f3 rd, HitInfo *hp, Closest *bp, int *prim_hit_p, oracle_counters *cn, int level) {
+    HitInfo h = *hp;
+    Closest best = *bp;
+    int prim_hit = -1;
         for (int i = 0; i < sc->n_prims; i++) {
             cn->prim_tests[level]++;
             if (intersectPrim(sc, &sc->prims[i], ro, rd, &h) && h.t < best.tMin) {
@@ -562,6 +544,34 @@ static f3 shadePixel(const oracle_scene *sc, f3 primaryDir, int32_t *hit_id, ora
                 }
             }
         }
+    *hp = h; *bp = best; *prim_hit_p = prim_hit;
+}
+
+typedef struct { int valid; f3 ro, rd, color; float kReflect, kRefract; } TreeNode;
+
+#define MAX_TREE 255
+
+/* One fragment. Returns the colour; *hit_id = id of what the primary ray hit. */
+static f3 shadePixel(const oracle_scene *sc, f3 primaryDir, int32_t *hit_id, oracle_counters *cn) {
+    TreeNode tree[MAX_TREE];
+    int size = (1 << sc->cfg.max_depth) - 1;
+    if (size > MAX_TREE) size = MAX_TREE;
+    memset(tree, 0, sizeof(TreeNode) * (size_t)size);
+    tree[0].valid = 1;
+    tree[0].ro = F3(sc->cam[0], sc->cam[1], sc->cam[2]);
+    tree[0].rd = normalize3(primaryDir);
+    *hit_id = -1;
+    for (int node = 0; node < size; ++node) {
+        if (!tree[node].valid) continue;
+        f3 ro = tree[node].ro, rd = tree[node].rd;
+        int level = 0; for (int n = node + 1; n > 1; n >>= 1) level++;
+        if (level > 7) level = 7;
+        cn->rays++; cn->rays_level[level]++;
+        Closest best; memset(&best, 0, sizeof best);
+        best.tMin = sc->cfg.infinity; best.face = -1;
+        int prim_hit = -1;
+        HitInfo h; memset(&h, 0, sizeof h);
+        findClosest(sc, ro, rd, &h, &best, &prim_hit, cn, level);
         if (h.hit) {
             h.t = best.tMin; h.normal = best.normal; h.localHitPoint = best.localHitPoint;
             h.hitPoint = best.hitPoint; h.materialType = best.materialType; h.materialId = best.materialId;
@@ -607,6 +617,54 @@ static f3 shadePixel(const oracle_scene *sc, f3 primaryDir, int32_t *hit_id, ora
         }
     }
     return tree[0].color;
+}
+
+/* Test access to the pieces of one ray-tree node, for known-answer tests: closest hit of an arbitrary ray, the local
+ * colour illuminate() gives it and the two child rays. out[0] = 1 on a hit, out[1] = analytic primitive index or
+ * n_prims + face, out[2] = t, out[3..5] = hit point, out[6..8] = normal as the shader holds it (not normalised),
+ * out[9..11] = object-space hit point, out[12..14] = local colour, out[15..17] = kReflect, kRefract, ior,
+ * out[18..23] = origin and direction of the refracted child, out[24..29] = of the reflected child (computed whatever
+ * the coefficients are), out[30] = number of lights whose shadow ray was blocked. */
+void oracle_probe(const oracle_scene *sc, const float *ro3, const float *rd3, float *out) {
+    oracle_counters cn; memset(&cn, 0, sizeof cn);
+    f3 ro = F3(ro3[0], ro3[1], ro3[2]), rd = F3(rd3[0], rd3[1], rd3[2]);
+    Closest best; memset(&best, 0, sizeof best);
+    best.tMin = sc->cfg.infinity; best.face = -1;
+    int prim_hit = -1;
+    HitInfo h; memset(&h, 0, sizeof h);
+    for (int i = 0; i < 31; i++) out[i] = 0.0f;
+    findClosest(sc, ro, rd, &h, &best, &prim_hit, &cn, 0);
+    if (!h.hit) return;
+    h.t = best.tMin; h.normal = best.normal; h.localHitPoint = best.localHitPoint;
+    h.hitPoint = best.hitPoint; h.materialType = best.materialType; h.materialId = best.materialId;
+    out[0] = 1.0f; out[1] = (float)((best.face >= 0) ? sc->n_prims + best.face : prim_hit); out[2] = h.t;
+    out[3] = h.hitPoint.x; out[4] = h.hitPoint.y; out[5] = h.hitPoint.z;
+    out[6] = h.normal.x; out[7] = h.normal.y; out[8] = h.normal.z;
+    out[9] = h.localHitPoint.x; out[10] = h.localHitPoint.y; out[11] = h.localHitPoint.z;
+    float kReflect = 0.0f, kRefract = 0.0f, ior = 0.0f;
+    f3 c = illuminate(sc, &h, rd, &kReflect, &kRefract, &ior, &cn, 0);
+    out[12] = c.x; out[13] = c.y; out[14] = c.z; out[15] = kReflect; out[16] = kRefract; out[17] = ior;
+    /* the child rays exactly as shadePixel forms them */
+    int outside = dot3(rd, h.normal) < 0.0f;
+    f3 bias = mul3(h.normal, sc->cfg.epsilon);
+    f3 o1 = outside ? sub3(h.hitPoint, bias) : add3(h.hitPoint, bias);
+    f3 N = outside ? h.normal : neg3(h.normal);
+    float eta = outside ? (1.0f / ior) : ior;
+    float cosi = dot3(neg3(N), rd);
+    float k = 1.0f + eta * eta * (cosi * cosi - 1.0f);
+    f3 d1 = add3(mul3(rd, eta), mul3(N, eta * cosi - sqrtf(k)));
+    f3 o2 = outside ? add3(h.hitPoint, bias) : sub3(h.hitPoint, bias);
+    f3 d2 = sub3(rd, mul3(h.normal, 2.0f * dot3(h.normal, rd)));
+    out[18] = o1.x; out[19] = o1.y; out[20] = o1.z; out[21] = d1.x; out[22] = d1.y; out[23] = d1.z;
+    out[24] = o2.x; out[25] = o2.y; out[26] = o2.z; out[27] = d2.x; out[28] = d2.y; out[29] = d2.z;
+    /* castShadow counts a mesh hit itself; analytic blockers are told apart by re-running the shadow rays */
+    int blocked = 0;
+    for (int i = 0; i < sc->n_lights_loop; i++) {
+        f3 Lp = F3(sc->lights[i].position[0], sc->lights[i].position[1], sc->lights[i].position[2]);
+        f3 S = normalize3(sub3(Lp, h.hitPoint));
+        blocked += castShadow(sc, add3(h.hitPoint, mul3(h.normal, sc->cfg.epsilon)), S, &cn, 0);
+    }
+    out[30] = (float)blocked;
 }
 
 static inline f3 mix3(f3 a, f3 b, float t) {   /* GLSL mix: a*(1-t) + b*t */
