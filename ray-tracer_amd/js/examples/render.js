@@ -4,6 +4,8 @@
 //   node render.js [--scene file.js] [--model models/bun_zipper_res4.ply] [--width W --height H] [--depth D]
 //                  [--ss S] [--time T] [--tr 0|1] [--frames N] [--mesh-material ka,kd,ks,ke,kReflect,kRefract,ior]
 //                  [--kd-builder host|device] [--split 1: update() as updateBegin() + updateEnd()]
+//                  [--pick x,y] [--drag x0,y0,x1,y1[,x2,y2...]: after the frame(s), click at (x0,y0), press again to grab,
+//                   move through the other positions, release, and render one more frame 0.5 s later]
 const fs = require('fs');
 const path = require('path');
 const crypto = require('crypto');
@@ -43,6 +45,23 @@ const sha = (u8) => crypto.createHash('sha256').update(Buffer.from(u8.buffer, u8
     const out = { width: G.WIDTH, height: G.HEIGHT, depth: G.MAX_RECURSION_DEPTH, model: G.MODEL_FILE_NAME, frames,
         Lbar: tracer.Lbar, sf: tracer.sf, rgba8_sha256: sha(tracer.pixels), canvas_sha256: sha(canvas),
         rays: st.raysTotal, shadow_rays: st.shadowRays, trace_ms: st.traceMs, kd_build_ms: st.kdBuildMs, wall_ms_per_frame: ms };
+    const dg = arg('drag', null);
+    if (dg) {
+        const d = dg.split(',').map(Number), ui = new G.UI(tracer);
+        ui.mouseDown(d[0], d[1]);
+        ui.mouseUp(d[0], d[1]);
+        out.drag_selected = ui.selectedObject ? ui.selectedObject.constructor.name : null;
+        out.drag_grabbed = ui.selectedObject ? ui.mouseDown(d[0], d[1]) && ui.moving : false;
+        for (let k = 2; k + 1 < d.length; k += 2) ui.mouseMove(d[k], d[k + 1]);
+        ui.mouseUp(d[d.length - 2], d[d.length - 1]);
+        if (ui.selectedObject) out.drag_model = Array.from(ui.selectedObject.modelTransform.elements);
+        const t1 = time + (frames - 1) / 60 + 0.5;      // past the rebuild interval: the tree follows the mesh
+        G.animate(scene, t1);
+        tracer.update(t1);
+        canvas = tracer.render();
+        out.drag_rgba8_sha256 = sha(tracer.pixels);
+        out.drag_canvas_sha256 = sha(canvas);
+    }
     const pk = arg('pick', null);   // --pick x,y (canvas pixel, y from the top): class name of the object under it
     if (pk) { const o = tracer.pick(...pk.split(',').map(Number)); out.picked = o ? o.constructor.name : null; }
     const ppm = arg('ppm', null);

@@ -2,7 +2,7 @@
 // Entry point of the JavaScript host. createContext(options) returns the global object of a fresh vm context
 // that holds what the reference's page script defines for a scene description (js/8-kd_tree.js): the constants
 // at the top of the script, `THREE` (three_lite.js), the scene classes, loadPLY / loadOBJ, the id counters,
-// g_verts / g_faces, `camera`, getPrimaryRay and class RayTracer. A scene script - an unchanged
+// g_verts / g_faces, `camera`, getPrimaryRay, class RayTracer and class UI (selecting and dragging objects, ui.js). A scene script - an unchanged
 // `function generateScene(meshes) {...}` - is evaluated inside that context with run().
 //
 //   const rt = require('ray-tracer_amd/js');
@@ -17,6 +17,7 @@ const path = require('path');
 const THREE = require('./three_lite.js');
 const { makeSceneAPI } = require('./scene.js');
 const { makeLoaders } = require('./loaders.js');
+const { makeUI } = require('./ui.js');
 
 // the constants of js/8-kd_tree.js:14-47 and the canvas of 8-kd_tree.html:11
 const DEFAULTS = {
@@ -47,7 +48,7 @@ function createContext(options) {
     G.g_faces = [];
     G.resolveAsset = (f) => (path.isAbsolute(f) ? f : path.join(G.ASSET_ROOT, f));
     const api = makeSceneAPI(G, THREE);
-    Object.assign(G, api, makeLoaders(G, THREE, api.Triangle));
+    Object.assign(G, api, makeLoaders(G, THREE, api.Triangle), makeUI(G, THREE, api));
     G.camera = new THREE.PerspectiveCamera(G.VIEW_ANGLE, G.WIDTH / G.HEIGHT, G.NEAR, G.FAR);
     // js/8-kd_tree.js:1094-1098
     G.getPrimaryRay = (x, y) => new THREE.Vector3(x, y, -1).unproject(G.camera).sub(G.camera.position).normalize();

@@ -56,9 +56,37 @@ rt.run(G, source, pageScript || 'default_scene.js');
     const tracer = new G.RayTracer();
     tracer.setScene(scene);
     tracer.prepare(man.time);
+    let frameTime = man.time;
+    if (man.drag) {
+        // the reference's ui.mouseDown / mouseMove / mouseUp were driven with these pixels; here the click's pick is
+        // replaced by its recorded result (picking needs a traced frame, this check runs without a GPU)
+        const d = man.drag, ui = new G.UI(tracer);
+        const near = (a, b) => a.length === b.length && a.every((x, i) => x === b[i]);
+        ui.select(scene.objects[d.selected_index]);
+        if (ui.mouseDown(d.mouse[0], d.mouse[1]) !== d.grab_returned || ui.moving !== d.moving) failures.push('drag: the press did not grab the object');
+        if (ui.zPos !== d.zPos) failures.push('drag: zPos ' + ui.zPos + ' != ' + d.zPos);
+        if (!near([ui.oldPosition.x, ui.oldPosition.y, ui.oldPosition.z], d.old_position)) failures.push('drag: oldPosition differs');
+        const got = [];
+        for (let k = 2; k + 1 < d.mouse.length; k += 2) {
+            ui.mouseMove(d.mouse[k], d.mouse[k + 1]);
+            got.push([ui.oldPosition.x, ui.oldPosition.y, ui.oldPosition.z]);
+        }
+        ui.mouseUp(d.mouse[d.mouse.length - 2], d.mouse[d.mouse.length - 1]);
+        got.push([ui.oldPosition.x, ui.oldPosition.y, ui.oldPosition.z]);
+        got.forEach((p, i) => { if (!near(p, d.positions[i])) failures.push('drag: position ' + i + ' = [' + p + '] want [' + d.positions[i] + ']'); });
+        const so = ui.selectedObject;
+        if (!near(Array.from(so.modelTransform.elements), d.model_after)) failures.push('drag: modelTransform differs');
+        if (!near(Array.from(so.invModelTransform.elements), d.inv_model_after)) failures.push('drag: invModelTransform differs');
+        frameTime = man.time + 0.5;     // the generator's next tick, past the rebuild throttle
+        G.animate(scene, frameTime);
+        tracer.prepare(frameTime);
+    }
 
+    // a uniform that was set several times (several ticks) is compared with its last value
+    const lastValue = new Map();
+    for (const u of man.uniforms) lastValue.set(u.name, u);
     let checked = 0;
-    for (const u of man.uniforms) {
+    for (const u of lastValue.values()) {
         if (!(u.name in tracer.uniforms)) continue;
         const v = tracer.uniforms[u.name];
         let got;
@@ -71,7 +99,7 @@ rt.run(G, source, pageScript || 'default_scene.js');
             failures.push('uniform ' + u.name + ': got [' + Array.from(got) + '] want [' + Array.from(want) + ']');
         }
     }
-    const expectNames = man.uniforms.map((u) => u.name).filter((n) => /^(model|invModel|phong|pointLights|ambientLight|bgColor|cameraPos|ray|kdBox)/.test(n));
+    const expectNames = man.uniforms.map((u) => u.name).filter((n) => /^(model\d|invModel|phong|pointLights|ambientLight|bgColor|cameraPos|ray|kdBox)/.test(n));   // modelViewProjection belongs to the selection-box overlay, which is not built
     for (const n of expectNames) if (!(n in tracer.uniforms)) failures.push('uniform ' + n + ' was not produced');
 
     const k = tracer._meshKey;

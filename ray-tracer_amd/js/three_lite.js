@@ -24,6 +24,8 @@ class Vector3 {
     }
     // r84 divides by multiplying with the reciprocal
     divideScalar(s) { return this.multiplyScalar(1 / s); }
+    divide(v) { this.x /= v.x; this.y /= v.y; this.z /= v.z; return this; }
+    setFromMatrixPosition(m) { const e = m.elements; this.x = e[12]; this.y = e[13]; this.z = e[14]; return this; }
     dot(v) { return this.x * v.x + this.y * v.y + this.z * v.z; }
     lengthSq() { return this.x * this.x + this.y * this.y + this.z * this.z; }
     length() { return Math.sqrt(this.x * this.x + this.y * this.y + this.z * this.z); }

@@ -32,16 +32,19 @@ def run_node(args, timeout=300):
 
 @needs_node
 @pytest.mark.parametrize("golden", ["k8_res4_640x480", "k8_res3_640x480", "c2_res4_1920x1080", "k8_full_640x480",
-                                    "k8_res4_teapot_640x480", "c3_bunny_teapot"])
+                                    "k8_res4_teapot_640x480", "c3_bunny_teapot", "k8_res4_drag_640x480"])
 def test_js_scene_matches_reference_capture(golden):
-    """The two *teapot fixtures add a second mesh through loadOBJ with REBASE_MESH_INDICES (BASELINE config 3 as benchmarked)."""
+    """The two *teapot fixtures add a second mesh through loadOBJ with REBASE_MESH_INDICES (BASELINE config 3 as benchmarked).
+    The drag fixture was made by driving the reference's UI.mouseDown / mouseMove / mouseUp: class UI (js/ui.js) must
+    grab the mesh at the same depth, follow the mouse through the same positions and leave the same transforms,
+    vertices and tree."""
     out = run_node([os.path.join(JS, "test", "check_golden.js"), os.path.join(GOLDEN, golden)])
     assert out["failures"] == [] and out["uniforms_checked"] >= 80
 
 
 @needs_node
 @pytest.mark.skipif(not os.path.exists(REF_SCRIPT), reason="reference checkout not present")
-@pytest.mark.parametrize("golden", ["k8_res4_640x480", "c2_res4_1920x1080", "k8_res4_teapot_640x480"])
+@pytest.mark.parametrize("golden", ["k8_res4_640x480", "c2_res4_1920x1080", "k8_res4_teapot_640x480", "k8_res4_drag_640x480"])
 def test_unchanged_reference_generate_scene_runs(golden):
     """generateScene() is read from the reference's page script at test time and evaluated as it is."""
     out = run_node([os.path.join(JS, "test", "check_golden.js"), os.path.join(GOLDEN, golden), REF_SCRIPT])
@@ -115,3 +118,56 @@ def test_js_animation_same_frames_with_either_builder():
     assert dev["last_canvas_sha256"] == host["last_canvas_sha256"]
     one = run_node(args + ["--kd-builder", "device", "--tracers", "1", "--frames", "7"])   # same last frame index
     assert one["last_canvas_sha256"] == dev["last_canvas_sha256"]
+
+
+def _dragged_flat(m, width=640, height=480, depth=3):
+    """The scene of the drag fixture after the drag, built with the Python scene twin: the mesh translated by the
+    differences of the recorded positions (UI.mouseMove / mouseUp translate by newPosition - oldPosition,
+    js/8-kd_tree.js:2771, :2785), the light at the following tick's time."""
+    from ray_tracer_amd import abi, scene
+    from ray_tracer_amd.three_f32 import Vector3
+    from helpers import model
+    mm = tuple(float(v) for v in m["constant_edits"]["meshMaterial"].split(","))
+    sc = scene.default_scene(model("bun_zipper_res4.ply"), mesh_material=mm)
+    mesh = sc.objects[m["drag"]["selected_index"]]
+    old = m["drag"]["old_position"]
+    for pos in m["drag"]["positions"]:
+        mesh.translate(Vector3(pos[0] - old[0], pos[1] - old[1], pos[2] - old[2]))
+        old = pos
+    scene.animate_light(sc, m["time"] + 0.5)
+    return abi.FlatScene(sc, abi.default_config(width, height, depth=depth), scene.camera_rays(width, height)), mesh
+
+
+def test_python_scene_twin_reproduces_the_dragged_mesh():
+    from helpers import manifest, sha
+    m = manifest("k8_res4_drag_640x480")
+    flat, mesh = _dragged_flat(m)
+    assert [float(np.float32(v)) for v in mesh.modelTransform.toArray()] == m["drag"]["model_after"]
+    assert sha(flat.verts) == m["sha256"]["verts_f64"] and sha(flat.faces) == m["sha256"]["faces_u32"]
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_drag_the_mesh_and_render_equals_oracle():
+    """The bunny clicked (picked from the hit-id buffer), grabbed and dragged with class UI from JavaScript, then one
+    more frame: the mesh must have moved exactly as the reference's UI moved it (fixture), and the frame after the drag
+    must equal the oracle's render of the moved scene byte for byte."""
+    from helpers import manifest
+    from oracle import oracle
+    from ray_tracer_amd import abi
+    m = manifest("k8_res4_drag_640x480")
+    d = m["drag"]
+    out = run_node([os.path.join(JS, "examples", "render.js"), "--width", "640", "--height", "480", "--depth", "3",
+                    "--mesh-material", m["constant_edits"]["meshMaterial"], "--time", str(m["time"]),
+                    "--drag", ",".join(str(v) for v in d["mouse"])])
+    assert out["drag_selected"] == "Mesh" and out["drag_grabbed"] is True
+    assert out["drag_model"] == d["model_after"]
+    flat, _ = _dragged_flat(m)
+    want_f, want_8, want_id, _ = oracle.OracleRenderer(flat).trace(threads=16)
+    assert out["drag_rgba8_sha256"] == hashlib.sha256(np.ascontiguousarray(want_8).tobytes()).hexdigest()
+    rt = abi.RayTracerHIP(flat.cfg)
+    rt.setScene(flat, kd_on_device=True)
+    rt.trace()
+    assert np.array_equal(rt.readRGBA8(), want_8) and np.array_equal(rt.readHitIds(), want_id)
+    assert out["drag_rgba8_sha256"] != out["rgba8_sha256"]      # the frame did change
+    rt.close()
