@@ -524,6 +524,11 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
         const bool pop = cont && sp_top != sp_lo;
         uint2 e = make_uint2(0u, __float_as_uint(maxDist));   // ring ran dry: restart at the root up to maxDist
         if (pop) e = stack[((uint32_t)(sp_top - 1) & (SHORT_STACK - 1)) * WAVE];
+        // both children of an internal node sit in one aligned 16-byte slot pair (a popped node shares such a pair with
+        // its sibling): the load is issued before the plane distance is known and the choice is made in registers,
+        // which takes the division out of the dependent chain of a ray (what a launch over few rays waits for)
+        uint4 pair = make_uint4(0u, 0u, 0u, 0u);
+        if (is_int || cont) pair = *reinterpret_cast<const uint4 *>(nodes + (is_int ? (info & 0x0fffffffu) : (e.x & ~1u)));
         // internal node: classify the children and pick the side(s) the ray interval touches
         const uint32_t a = (info >> 28) & 3u;
         const float o = a == 0u ? ox : (a == 1u ? oy : oz), d = a == 0u ? dx : (a == 1u ? dy : dz);
@@ -546,9 +551,9 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
         next = cont ? e.x : next;
         info = 0u;
         if (is_int || cont) {
-            const KdNodeDev n = nodes[next];
-            info = n.info;
-            split = n.split;
+            const bool upper = (next & 1u) != 0u;
+            split = __uint_as_float(upper ? pair.z : pair.x);
+            info = upper ? pair.w : pair.y;
         }
 
         // ---- the leaves just entered: one record per non-empty leaf into the wave's ring
