@@ -738,15 +738,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
     }
     int32_t slot_refl = -1, slot_refr = -1;
     if (!A.last_level) {
-        // the refracted ray takes the lane's first slot, the reflected one the next
-        uint32_t cs = block_reserve((want_refr ? 1u : 0u) + (want_refl ? 1u : 0u), &A.cnt->next_count, s_wave);
-        if (want_refr) {
-            if (cs < A.nxt_cap) {
-                slot_refr = (int32_t)cs;
-                store_ray(A.nxt.ray, cs, c_refr_o, c_refr_d);
-            }
-            cs++;
+        // the refracted rays of the workgroup take one run of slots, the reflected ones the next: neighbours in the
+        // queue then are rays of one kind from neighbouring pixels, which walk the same part of the tree
+        uint32_t cs = block_reserve(want_refr ? 1u : 0u, &A.cnt->next_count, s_wave);
+        if (want_refr && cs < A.nxt_cap) {
+            slot_refr = (int32_t)cs;
+            store_ray(A.nxt.ray, cs, c_refr_o, c_refr_d);
         }
+        cs = block_reserve(want_refl ? 1u : 0u, &A.cnt->next_count, s_wave);
         if (want_refl && cs < A.nxt_cap) {
             slot_refl = (int32_t)cs;
             store_ray(A.nxt.ray, cs, c_refl_o, c_refl_d);
@@ -770,19 +769,18 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
             A.hit_ids[(size_t)py * A.g.W + px] = sf.hit_id;
         }
     }
-    // shadow rays that must walk the tree: one reservation for the whole workgroup
-    uint32_t slot = block_reserve((uint32_t)__popc(kd_mask), &A.cnt->shq_count, s_wave);
-    while (kd_mask) {
-        const int l = __ffs((int)kd_mask) - 1;
-        kd_mask &= kd_mask - 1;
-        if (slot < A.shq_cap) {
+    // shadow rays that must walk the tree: one reservation per light for the whole workgroup, so that a run of the
+    // queue holds rays towards ONE light from neighbouring surface points (they cross the same cells)
+    for (int l = 0; l < S.n_lights; l++) {
+        const bool mine = (kd_mask >> l) & 1u;
+        const uint32_t slot = block_reserve(mine ? 1u : 0u, &A.cnt->shq_count, s_wave);
+        if (mine && slot < A.shq_cap) {
             const V3 sd = shadow_dir(S, l, sf.point);
             float t0, t1;
             ray_box(S, so, sd, t0, t1);
             store_ray(A.shq.ray, slot, so, sd, t0, t1);
             A.shq.id[slot] = (tid << 5) | (uint32_t)l;
         }
-        slot++;
     }
 }
 
