@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap,
     const uint32_t heap = leaf_heap[i], code = code_of_heap(heap), cnt = leaf_count[i];
     const unsigned long long x = code_scan[~code & (CODES - 1u)];
     const uint32_t first = (uint32_t)x, number = (uint32_t)(x >> 32);
-    if (leaf_pos[i] < node_cap) nodes[leaf_pos[i]] = KdNodeDev{0.0f, T_LEAF | (cnt << LEAF_COUNT_SHIFT) | first};
+    if (leaf_pos[i] < node_cap) nodes[leaf_pos[i]] = KdNodeDev{0.0f, leaf_info(cnt, first)};
     path_slot[code] = first;
     for (uint32_t k = 0; k < 4u; k++) {
         const uint32_t f = leaf_faces[4 * (size_t)i + k];

@@ -67,9 +67,14 @@ inline uint32_t path_code(uint32_t heap) {
 }
 
 // Device copy of a k-d node (see kd_build.h for internal nodes). Leaf info differs from the host form:
-// [31:30] = 3, [29:27] = number of faces (1..4), [26:0] = first slot in `ltris`.
-constexpr uint32_t LEAF_COUNT_SHIFT = 27;
+// [31:30] = 3, [25:24] = number of faces - 1 (a leaf with faces has 1..4), [23:0] = first slot in `ltris`.
+// The low 26 bits are, as they stand, the record a walking lane puts into its wave's ring of pending triangle tests.
+constexpr uint32_t LEAF_COUNT_SHIFT = 24;
 constexpr uint32_t LEAF_SLOT_MASK = (1u << LEAF_COUNT_SHIFT) - 1u;
+constexpr uint32_t LEAF_RECORD_MASK = (1u << 26) - 1u;
+__host__ __device__ inline uint32_t leaf_info(uint32_t n_faces, uint32_t first_slot) {
+    return (3u << 30) | ((n_faces - 1u) << LEAF_COUNT_SHIFT) | first_slot;
+}
 
 struct SceneDev {
     int32_t n_prims, n_mats, n_lights, n_faces;

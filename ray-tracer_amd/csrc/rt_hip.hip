@@ -234,7 +234,7 @@ int device_build(rt_ctx *ctx) {
         ctx->err = "rt_build_kdtree_device: " + err;
         return -1;
     }
-    if (ctx->gpu_kd->tree.n_slots > (1u << RING_SLOT_BITS)) return fail(ctx, "rt_build_kdtree_device: k-d tree has too many leaf slots for the device layout (2^24)");
+    if (ctx->gpu_kd->tree.n_slots > (1u << LEAF_COUNT_SHIFT)) return fail(ctx, "rt_build_kdtree_device: k-d tree has too many leaf slots for the device layout (2^24)");
     ctx->st.kd_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->st.kd_upload_ms = 0.0;
     return 0;
@@ -309,7 +309,7 @@ int upload_scene(rt_ctx *ctx) {
             for (int k = 0; k < 4; k++) c += kd.leaves[i].face[k] > -1;
             first[i + 1] = first[i] + c;
         }
-        if (first.back() > (1u << RING_SLOT_BITS)) return fail(ctx, "k-d tree has too many leaf slots for the device layout (2^24)");
+        if (first.back() > (1u << LEAF_COUNT_SHIFT)) return fail(ctx, "k-d tree has too many leaf slots for the device layout (2^24)");
         std::vector<TriDev> ltris(first.back());
         for (size_t i = 0; i < kd.leaves.size(); i++) {
             uint32_t s0 = first[i];
@@ -323,7 +323,7 @@ int upload_scene(rt_ctx *ctx) {
             KdNodeDev &n = nodes[s];
             if ((n.info >> 30) == 3u) {
                 const uint32_t li = n.info & 0x3fffffffu;
-                n.info = (3u << 30) | ((first[li + 1] - first[li]) << LEAF_COUNT_SHIFT) | first[li];
+                n.info = leaf_info(first[li + 1] - first[li], first[li]);
                 const uint32_t code = path_code(kd.heap_index[s]);
                 for (uint32_t k = first[li]; k < first[li + 1]; k++) ltris[k].code = code;
                 path_first.push_back(make_uint2(code, first[li]));

@@ -281,10 +281,9 @@ static_assert(RT_REFILL_CHUNK >= 64, "REFILL_CHUNK must be at least the wave siz
 constexpr int REFILL_CHUNK = RT_REFILL_CHUNK;        // rays a wave reserves from the global queue per atomic
 constexpr int SHORT_STACK = RT_SHORT_STACK;          // power of two
 constexpr int MAIL_SLOTS = 32;                       // stretches that change hands in one exchange of a wave
-// leaf records waiting for their triangle tests: lane << 26 | (faces - 1) << 24 | first slot in S.ltris.
+// leaf records waiting for their triangle tests: lane << 26 | the low 26 bits of the leaf's info ((faces - 1) << 24 | first slot in S.ltris).
 // The ring never holds more than 63 records when a round of the walk starts, and a round adds at most 64.
 constexpr int TEST_RING = 128;
-constexpr uint32_t RING_SLOT_BITS = 24;              // the leaf-ordered triangle table may hold 2^24 slots
 #ifndef RT_TEST_MIN_DRY
 #define RT_TEST_MIN_DRY 64
 #endif
@@ -308,7 +307,7 @@ __device__ __forceinline__ bool test_round(const SceneDev &S, const WalkJob &J, 
     const bool act = lane < n;
     const uint32_t rec = act ? ring[(head + lane) & (uint32_t)(TEST_RING - 1)] : 0u;
     const int src = (int)(rec >> 26);
-    const uint32_t first = rec & ((1u << RING_SLOT_BITS) - 1u), count = ((rec >> RING_SLOT_BITS) & 3u) + 1u;
+    const uint32_t first = rec & LEAF_SLOT_MASK, count = ((rec >> LEAF_COUNT_SHIFT) & 3u) + 1u;
     // Lanes beyond n (only when the ring is drained with fewer than 64 records) run the same code on slot 0 and
     // lane 0's ray and drop the result: with no branch around the arithmetic the triangle loads are issued first and
     // the permutes and the other lanes' work run under their latency
@@ -543,7 +542,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
         // leaf with faces: note it (below), then go on with the next cell of the ray
         const bool is_listed = info >= 0xc0000000u;
         const unsigned long long listed = __builtin_amdgcn_ballot_w64(is_listed);
-        const uint32_t leaf_info = info;
+        const uint32_t at_info = info;
         sp_top += both ? 1 : (pop ? -1 : 0);                  // a push and a pop never meet in one action
         sp_lo = max(sp_lo, sp_top - SHORT_STACK);             // a push onto a full ring drops the oldest entry
         tmin = cont ? tmax : tmin;
@@ -560,8 +559,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
         if (listed) {
             if (is_listed) {
                 const uint32_t pos = ring_tail + RANK_IN(listed);
-                ring[pos & (uint32_t)(TEST_RING - 1)] = (lane << 26) | ((((leaf_info >> LEAF_COUNT_SHIFT) & 7u) - 1u) << RING_SLOT_BITS) |
-                                                         (leaf_info & ((1u << RING_SLOT_BITS) - 1u));
+                ring[pos & (uint32_t)(TEST_RING - 1)] = (lane << 26) | (at_info & LEAF_RECORD_MASK);
                 my_last = pos + 1u;
             }
             ring_tail = UNIFORM(ring_tail + COUNT_OF(listed));
