@@ -280,10 +280,20 @@ constexpr int REFILL_MIN_IDLE = RT_REFILL_MIN_IDLE;   // refill once this many l
 static_assert(RT_REFILL_CHUNK >= 64, "REFILL_CHUNK must be at least the wave size");
 constexpr int REFILL_CHUNK = RT_REFILL_CHUNK;        // rays a wave reserves from the global queue per atomic
 constexpr int SHORT_STACK = RT_SHORT_STACK;          // power of two
-constexpr int MAIL_SLOTS = 32;                       // stretches that change hands in one exchange of a wave
+#ifndef RT_MAIL_SLOTS
+#define RT_MAIL_SLOTS 32
+#endif
+constexpr int MAIL_SLOTS = RT_MAIL_SLOTS;                      // stretches that change hands in one exchange of a wave
 // leaf records waiting for their triangle tests: lane << 26 | the low 26 bits of the leaf's info ((faces - 1) << 24 | first slot in S.ltris).
-// The ring never holds more than 63 records when a round of the walk starts, and a round adds at most 64.
-constexpr int TEST_RING = 128;
+// The ring never holds more than 63 records when the lanes take their next actions.
+constexpr int TEST_RING = 256;
+#ifndef RT_WALK_ACTIONS
+#define RT_WALK_ACTIONS 2
+#endif
+// tree actions per lane between two looks at the ring and at the number of idle lanes (the look costs about a sixth of
+// an action); a look finds at most 63 records left over and WALK_ACTIONS * 64 new ones
+constexpr int WALK_ACTIONS = RT_WALK_ACTIONS;
+static_assert(63 + WALK_ACTIONS * 64 <= TEST_RING, "the ring must hold what the actions between two looks can list");
 #ifndef RT_TEST_MIN_DRY
 #define RT_TEST_MIN_DRY 64
 #endif
@@ -377,19 +387,16 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
 #endif
 
     for (;;) {
-        // ---- triangle tests: a full round as soon as 64 records wait; what is left when no lane walks any more
-        {
+        // ---- triangle tests: full rounds as long as 64 records wait; what is left when no lane walks any more
+        for (;;) {
             const uint32_t waiting = UNIFORM(ring_tail - ring_head);
-            if (waiting != 0u) {
-                const bool nobody_walks = __builtin_amdgcn_ballot_w64(info != 0u) == 0ull;
-                if (waiting >= (UNIFORM(more) ? (uint32_t)WAVE : TEST_MIN_DRY) || nobody_walks) {
-                    const uint32_t n = min(waiting, (uint32_t)WAVE);
-                    const bool mine = test_round<ANY>(S, J, ring, hit_flag, ring_head, n, lane, ox, oy, oz, dx, dy, dz, ref);
-                    ring_head = UNIFORM(ring_head + n);
-                    n_records += n;
-                    if (ANY && mine) info = 0u;   // occluded: whatever else lies along the ray cannot change the bit
-                }
-            }
+            if (waiting == 0u) break;
+            if (waiting < (UNIFORM(more) ? (uint32_t)WAVE : TEST_MIN_DRY) && __builtin_amdgcn_ballot_w64(info != 0u) != 0ull) break;
+            const uint32_t n = min(waiting, (uint32_t)WAVE);
+            const bool mine = test_round<ANY>(S, J, ring, hit_flag, ring_head, n, lane, ox, oy, oz, dx, dy, dz, ref);
+            ring_head = UNIFORM(ring_head + n);
+            n_records += n;
+            if (ANY && mine) info = 0u;   // occluded: whatever else lies along the ray cannot change the bit
         }
         // ---- refill: while the global queue has rays, as soon as enough lanes are free. A lane is free when its ray
         //      is finished AND none of its records is still waiting in the ring (those name its ray registers)
@@ -507,62 +514,65 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
             }
         }
 
-        // ---- one tree action per walking lane, written as straight-line predicated code: nested branches cost
-        //      a handful of scalar exec-mask instructions each, and a CU issues only about 1.5 instructions per
-        //      cycle whatever their kind, so the instruction count of this block is what the walk costs.
-        //      info: [31:30] type (1 internal, 2 empty leaf, 3 leaf) - the sign bit says "leaf of either kind"
+#pragma unroll
+        for (int rep = 0; rep < WALK_ACTIONS; rep++) {
+            // ---- one tree action per walking lane, written as straight-line predicated code: nested branches cost
+            //      a handful of scalar exec-mask instructions each, and a CU issues only about 1.5 instructions per
+            //      cycle whatever their kind, so the instruction count of this block is what the walk costs.
+            //      info: [31:30] type (1 internal, 2 empty leaf, 3 leaf) - the sign bit says "leaf of either kind"
 #ifdef RT_WALK_STATS
-        st_iters++;
-        st_visits += (unsigned long long)__popcll(__ballot(info != 0u));
+            st_iters++;
+            st_visits += (unsigned long long)__popcll(__ballot(info != 0u));
 #endif
-        const bool at_leaf = (int32_t)info < 0;
-        const bool is_int = info != 0u && !at_leaf;
-        // a lane at a leaf goes on with the newest entry of its stack. The entry is fetched first: the LDS read then
-        // runs under the arithmetic of the lanes at internal nodes instead of in front of the node fetch
-        const bool cont = at_leaf && tmax < maxDist;   // false on the last cell and on a NaN interval
-        const bool pop = cont && sp_top != sp_lo;
-        uint2 e = make_uint2(0u, __float_as_uint(maxDist));   // ring ran dry: restart at the root up to maxDist
-        if (pop) e = stack[((uint32_t)(sp_top - 1) & (SHORT_STACK - 1)) * WAVE];
-        // both children of an internal node sit in one aligned 16-byte slot pair (a popped node shares such a pair with
-        // its sibling): the load is issued before the plane distance is known and the choice is made in registers,
-        // which takes the division out of the dependent chain of a ray (what a launch over few rays waits for)
-        uint4 pair = make_uint4(0u, 0u, 0u, 0u);
-        if (is_int || cont) pair = *reinterpret_cast<const uint4 *>(nodes + (is_int ? (info & 0x0fffffffu) : (e.x & ~1u)));
-        // internal node: classify the children and pick the side(s) the ray interval touches
-        const uint32_t a = (info >> 28) & 3u;
-        const float o = a == 0u ? ox : (a == 1u ? oy : oz), d = a == 0u ? dx : (a == 1u ? dy : dz);
-        const float t = (split - o) / d;
-        const uint32_t child = info & 0x0fffffffu;
-        const uint32_t neg = d <= 0.0f ? 1u : 0u;
-        const uint32_t nearc = child + neg, farc = child + 1u - neg;
-        const bool ge = t >= tmax, le = t <= tmin;
-        const bool both = is_int && !ge && !le;
-        uint32_t next = (le && !ge) ? farc : nearc;
-        if (both) stack[((uint32_t)sp_top & (SHORT_STACK - 1)) * WAVE] = make_uint2(farc, __float_as_uint(tmax));
-        // leaf with faces: note it (below), then go on with the next cell of the ray
-        const bool is_listed = info >= 0xc0000000u;
-        const unsigned long long listed = __builtin_amdgcn_ballot_w64(is_listed);
-        const uint32_t at_info = info;
-        sp_top += both ? 1 : (pop ? -1 : 0);                  // a push and a pop never meet in one action
-        sp_lo = max(sp_lo, sp_top - SHORT_STACK);             // a push onto a full ring drops the oldest entry
-        tmin = cont ? tmax : tmin;
-        tmax = cont ? __uint_as_float(e.y) : (both ? t : tmax);
-        next = cont ? e.x : next;
-        info = 0u;
-        if (is_int || cont) {
-            const bool upper = (next & 1u) != 0u;
-            split = __uint_as_float(upper ? pair.z : pair.x);
-            info = upper ? pair.w : pair.y;
-        }
-
-        // ---- the leaves just entered: one record per non-empty leaf into the wave's ring
-        if (listed) {
-            if (is_listed) {
-                const uint32_t pos = ring_tail + RANK_IN(listed);
-                ring[pos & (uint32_t)(TEST_RING - 1)] = (lane << 26) | (at_info & LEAF_RECORD_MASK);
-                my_last = pos + 1u;
+            const bool at_leaf = (int32_t)info < 0;
+            const bool is_int = info != 0u && !at_leaf;
+            // a lane at a leaf goes on with the newest entry of its stack. The entry is fetched first: the LDS read then
+            // runs under the arithmetic of the lanes at internal nodes instead of in front of the node fetch
+            const bool cont = at_leaf && tmax < maxDist;   // false on the last cell and on a NaN interval
+            const bool pop = cont && sp_top != sp_lo;
+            uint2 e = make_uint2(0u, __float_as_uint(maxDist));   // ring ran dry: restart at the root up to maxDist
+            if (pop) e = stack[((uint32_t)(sp_top - 1) & (SHORT_STACK - 1)) * WAVE];
+            // both children of an internal node sit in one aligned 16-byte slot pair (a popped node shares such a pair with
+            // its sibling): the load is issued before the plane distance is known and the choice is made in registers,
+            // which takes the division out of the dependent chain of a ray (what a launch over few rays waits for)
+            uint4 pair = make_uint4(0u, 0u, 0u, 0u);
+            if (is_int || cont) pair = *reinterpret_cast<const uint4 *>(nodes + (is_int ? (info & 0x0fffffffu) : (e.x & ~1u)));
+            // internal node: classify the children and pick the side(s) the ray interval touches
+            const uint32_t a = (info >> 28) & 3u;
+            const float o = a == 0u ? ox : (a == 1u ? oy : oz), d = a == 0u ? dx : (a == 1u ? dy : dz);
+            const float t = (split - o) / d;
+            const uint32_t child = info & 0x0fffffffu;
+            const uint32_t neg = d <= 0.0f ? 1u : 0u;
+            const uint32_t nearc = child + neg, farc = child + 1u - neg;
+            const bool ge = t >= tmax, le = t <= tmin;
+            const bool both = is_int && !ge && !le;
+            uint32_t next = (le && !ge) ? farc : nearc;
+            if (both) stack[((uint32_t)sp_top & (SHORT_STACK - 1)) * WAVE] = make_uint2(farc, __float_as_uint(tmax));
+            // leaf with faces: note it (below), then go on with the next cell of the ray
+            const bool is_listed = info >= 0xc0000000u;
+            const unsigned long long listed = __builtin_amdgcn_ballot_w64(is_listed);
+            const uint32_t at_info = info;
+            sp_top += both ? 1 : (pop ? -1 : 0);                  // a push and a pop never meet in one action
+            sp_lo = max(sp_lo, sp_top - SHORT_STACK);             // a push onto a full ring drops the oldest entry
+            tmin = cont ? tmax : tmin;
+            tmax = cont ? __uint_as_float(e.y) : (both ? t : tmax);
+            next = cont ? e.x : next;
+            info = 0u;
+            if (is_int || cont) {
+                const bool upper = (next & 1u) != 0u;
+                split = __uint_as_float(upper ? pair.z : pair.x);
+                info = upper ? pair.w : pair.y;
             }
-            ring_tail = UNIFORM(ring_tail + COUNT_OF(listed));
+
+            // ---- the leaves just entered: one record per non-empty leaf into the wave's ring
+            if (listed) {
+                if (is_listed) {
+                    const uint32_t pos = ring_tail + RANK_IN(listed);
+                    ring[pos & (uint32_t)(TEST_RING - 1)] = (lane << 26) | (at_info & LEAF_RECORD_MASK);
+                    my_last = pos + 1u;
+                }
+                ring_tail = UNIFORM(ring_tail + COUNT_OF(listed));
+            }
         }
     }
     if (lane == 0 && n_records) atomicAdd(&J.cnt->rec_count[ANY ? 1 : 0], n_records);
