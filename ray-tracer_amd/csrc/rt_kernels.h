@@ -7,21 +7,20 @@
 //
 //   k_gen_prims    one lane per ray: (level 0: generate the primary ray) closest hit over the analytic
 //                  primitives; rays whose interval overlaps the k-d root box go to the walk queue
-//   k_kd_walk      persistent waves walk the tree for the queued rays and only LIST the leaves they cross, as
-//                  (ray, leaf's triangle slots) records; one launch serves the closest-hit rays of a level and
-//                  the shadow rays of the level before it
-//   k_tri_test     one lane per record: Moller-Trumbore; closest hit: 64-bit atomic min per ray of (t, visit rank
-//                  of the leaf, face position); shadow: any hit sets the light's shadow bit of the ray
+//   k_kd_walk      persistent waves walk the tree for the queued rays; the leaves a lane crosses are noted in a
+//                  ring in LDS and their triangles tested 64 records at a time by the whole wave (Moller-Trumbore;
+//                  closest hit: 64-bit atomic min per ray of (t, visit rank of the leaf, face position); shadow: any
+//                  hit sets the light's shadow bit of the ray and ends its walk); one launch serves the closest-hit
+//                  rays of a level and the shadow rays of the level before it
 //   k_shade_a      one lane per ray: resolves the mesh hit, miss -> background, hit -> the two children into the
 //                  next level's queue and one shadow ray per light: analytic any-hit test here, survivors that
 //                  reach the k-d box go to the shadow queue
 //   k_shade_b      one lane per ray, one step later: Phong terms with the finished shadow bits
 //
-// Walking and testing can be separated because the reference's closest-hit search never stops early: it
+// Walking and testing can be decoupled because the reference's closest-hit search never stops early: it
 // crosses every cell of the root interval and keeps the minimum t (js/8-kd_tree.js:862-962), so which
 // leaves are visited does not depend on any triangle test. For shadow rays the reference stops at the first
-// hit (js/8-kd_tree.js:685-687); walking on changes no result (any hit anywhere on the ray sets the same bit), and
-// testing in bulk afterwards measured faster than stopping lanes inside the walk (parked lanes idle the wave).
+// hit (js/8-kd_tree.js:685-687); where the walk stops changes no result (any hit anywhere on the ray sets the same bit).
 //
 // Each parent remembers the queue slots of its two children; k_composite then folds colours level by
 // level in the reference's order (refracted child first, then reflected: js/8-kd_tree.js:1041-1054 walks
@@ -272,6 +271,10 @@ struct WalkArgs {
 #define RT_WALK_WAVES_PER_CU 24
 #endif
 constexpr int REFILL_MIN_IDLE = RT_REFILL_MIN_IDLE;   // refill once this many lanes of the wave have no ray
+#ifndef RT_STEAL_MIN_IDLE
+#define RT_STEAL_MIN_IDLE 24
+#endif
+constexpr int STEAL_MIN_IDLE = RT_STEAL_MIN_IDLE;     // once the queue is dry: idle lanes that make the wave redistribute its rays
 #ifndef RT_REFILL_CHUNK
 #define RT_REFILL_CHUNK 64
 #endif
@@ -402,7 +405,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
         //      is finished AND none of its records is still waiting in the ring (those name its ray registers)
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(info == 0u && (int32_t)(my_last - ring_head) <= 0);
         const uint32_t n_idle = COUNT_OF(idle);
-        if (n_idle >= (uint32_t)REFILL_MIN_IDLE) {
+        if (n_idle >= (UNIFORM(more) ? (uint32_t)REFILL_MIN_IDLE : (uint32_t)STEAL_MIN_IDLE)) {
             if (!UNIFORM(more)) {
                 if (n_idle == (uint32_t)WAVE) break;
 #ifndef RT_NO_STEAL
@@ -535,19 +538,19 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
             // both children of an internal node sit in one aligned 16-byte slot pair (a popped node shares such a pair with
             // its sibling): the load is issued before the plane distance is known and the choice is made in registers,
             // which takes the division out of the dependent chain of a ray (what a launch over few rays waits for)
-            uint4 pair = make_uint4(0u, 0u, 0u, 0u);
-            if (is_int || cont) pair = *reinterpret_cast<const uint4 *>(nodes + (is_int ? (info & 0x0fffffffu) : (e.x & ~1u)));
+            // (every lane fetches: a lane without a ray or at the end of its ray has e.x = 0 and reads the root's pair)
+            const uint4 pair = *reinterpret_cast<const uint4 *>(nodes + (is_int ? (info & 0x0fffffffu) : (e.x & ~1u)));
             // internal node: classify the children and pick the side(s) the ray interval touches
             const uint32_t a = (info >> 28) & 3u;
             const float o = a == 0u ? ox : (a == 1u ? oy : oz), d = a == 0u ? dx : (a == 1u ? dy : dz);
             const float t = (split - o) / d;
             const uint32_t child = info & 0x0fffffffu;
-            const uint32_t neg = d <= 0.0f ? 1u : 0u;
-            const uint32_t nearc = child + neg, farc = child + 1u - neg;
+            const bool neg = d <= 0.0f;                              // the near child is the upper one
             const bool ge = t >= tmax, le = t <= tmin;
             const bool both = is_int && !ge && !le;
-            uint32_t next = (le && !ge) ? farc : nearc;
-            if (both) stack[((uint32_t)sp_top & (SHORT_STACK - 1)) * WAVE] = make_uint2(farc, __float_as_uint(tmax));
+            // which of the pair the lane goes on with is decided on wave masks: the far child alone = the other one
+            const bool upper = cont ? (e.x & 1u) != 0u : ((le && !ge) != neg);
+            if (both) stack[((uint32_t)sp_top & (SHORT_STACK - 1)) * WAVE] = make_uint2(child + (neg ? 0u : 1u), __float_as_uint(tmax));
             // leaf with faces: note it (below), then go on with the next cell of the ray
             const bool is_listed = info >= 0xc0000000u;
             const unsigned long long listed = __builtin_amdgcn_ballot_w64(is_listed);
@@ -556,22 +559,21 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
             sp_lo = max(sp_lo, sp_top - SHORT_STACK);             // a push onto a full ring drops the oldest entry
             tmin = cont ? tmax : tmin;
             tmax = cont ? __uint_as_float(e.y) : (both ? t : tmax);
-            next = cont ? e.x : next;
             info = 0u;
             if (is_int || cont) {
-                const bool upper = (next & 1u) != 0u;
                 split = __uint_as_float(upper ? pair.z : pair.x);
                 info = upper ? pair.w : pair.y;
             }
 
-            // ---- the leaves just entered: one record per non-empty leaf into the wave's ring
-            if (listed) {
+            // ---- the leaves just entered: one record per non-empty leaf into the wave's ring (some lane lists in
+            //      nearly every action, so there is no branch around this)
+            {
+                const uint32_t pos = ring_tail + RANK_IN(listed);
                 if (is_listed) {
-                    const uint32_t pos = ring_tail + RANK_IN(listed);
                     ring[pos & (uint32_t)(TEST_RING - 1)] = (lane << 26) | (at_info & LEAF_RECORD_MASK);
                     my_last = pos + 1u;
                 }
-                ring_tail = UNIFORM(ring_tail + COUNT_OF(listed));
+                ring_tail += (uint32_t)__builtin_popcountll(listed);
             }
         }
     }
