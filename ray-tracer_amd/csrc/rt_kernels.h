@@ -120,31 +120,23 @@ __device__ __forceinline__ void store_ray(float4 *ray, uint32_t i, V3 ro, V3 rd,
     ray[2 * (size_t)i + 1] = make_float4(rd.x, rd.y, rd.z, w1);
 }
 
-// Reserves `c` consecutive slots per lane in a global queue with ONE atomic per workgroup (an atomic per
-// wave on a single address serialises at roughly 10 ns each and was the floor of these kernels):
-// wave-level inclusive scan by shuffles, wave totals through LDS, the workgroup total added once.
-// Must be called by every lane of the workgroup. Returns the lane's first slot.
-__device__ __forceinline__ uint32_t block_reserve(uint32_t c, uint32_t *counter, uint32_t *s_wave /* [BLOCK/64 + 1] */) {
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    uint32_t incl = c;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const uint32_t v = __shfl_up(incl, o);
-        if (lane >= (uint32_t)o) incl += v;
-    }
-    if (lane == WAVE - 1) s_wave[wave] = incl;
+// Reserves one slot in a global queue for every lane that wants one, with ONE atomic per workgroup (an atomic per
+// wave on a single address serialises at roughly 10 ns each and was the floor of these kernels): a ballot gives the
+// lane's rank in its wave and the wave's count, the first lane adds up the waves and asks once.
+// Must be called by every lane of the workgroup, once per kernel (s_wave is not recycled). Returns the lane's slot.
+__device__ __forceinline__ uint32_t block_reserve(bool want, uint32_t *counter, uint32_t *s_wave /* [BLOCK/64 + 1] */) {
+    const uint32_t wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(want);
+    if (lane_id() == 0) s_wave[wave] = (uint32_t)__popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = 0;
         const uint32_t nw = blockDim.x >> 6;
         for (uint32_t w = 0; w < nw; w++) { const uint32_t t = s_wave[w]; s_wave[w] = total; total += t; }
-        const uint32_t base = total ? atomicAdd(counter, total) : 0u;
-        s_wave[nw] = base;
+        s_wave[nw] = total ? atomicAdd(counter, total) : 0u;
     }
     __syncthreads();
-    const uint32_t r = s_wave[blockDim.x >> 6] + s_wave[wave] + (incl - c);
-    __syncthreads();   // s_wave may be reused by the next call
-    return r;
+    return s_wave[blockDim.x >> 6] + s_wave[wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
 // root-box interval of a ray (js/8-kd_tree.js:545-573); the walk is needed when it is not empty: the reference's
@@ -207,7 +199,7 @@ __global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
         A.cur.hf[tid] = face;
         A.cur.best[tid] = ~0ull;
     }
-    const uint32_t slot = block_reserve(to_kd ? 1u : 0u, &A.cnt->kdq_count, s_wave);
+    const uint32_t slot = block_reserve(to_kd, &A.cnt->kdq_count, s_wave);
     if (to_kd) A.kdq[slot] = make_uint4(tid, __float_as_uint(kd_t0), __float_as_uint(kd_t1), 0u);
 }
 
@@ -655,7 +647,8 @@ __device__ __forceinline__ V3 shadow_dir(const SceneDev &S, int l, V3 point) {
 }
 
 __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
-    __shared__ uint32_t s_wave[BLOCK / WAVE + 1];
+    __shared__ uint32_t s_cnt[(3 + MAX_LIGHTS) * (BLOCK / WAVE)];   // per kind of emitted item and wave: count, then exclusive sum
+    __shared__ uint32_t s_base[2];                                  // first slot of the workgroup in the child / shadow queue
     const SceneDev &S = A.S;
     const uint32_t n_rays = level_rays(A.n_src, A.n_rays);
     if (blockIdx.x * BLOCK >= n_rays) return;
@@ -746,29 +739,54 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
             }
         }
     }
+    // Queue slots for everything this workgroup emits, with two barriers in all: per wave a ballot per kind gives the
+    // lane's rank and the wave's count; one lane adds up the waves of the children, another those of the shadow rays,
+    // each with ONE atomic on its queue's counter. Kinds: 0 refracted child, 1 reflected child, 2 shaded node (count
+    // only), 3 + l shadow ray towards light l that must walk the tree. The refracted rays of the workgroup take one run
+    // of slots, the reflected ones the next, then (in the shadow queue) one run per light: neighbours in a queue are
+    // rays of one kind from neighbouring pixels, which walk the same part of the tree.
+    constexpr uint32_t NW = BLOCK / WAVE;
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t n_kinds = 3u + (uint32_t)S.n_lights;
+    const unsigned long long m_refr = __ballot(want_refr), m_refl = __ballot(want_refl), m_hit = __ballot(hit);
+    if (lane == 0) {
+        s_cnt[0 * NW + wave] = (uint32_t)__popcll(m_refr);
+        s_cnt[1 * NW + wave] = (uint32_t)__popcll(m_refl);
+        s_cnt[2 * NW + wave] = (uint32_t)__popcll(m_hit);
+    }
+    for (int l = 0; l < S.n_lights; l++) {
+        const unsigned long long m = __ballot(((kd_mask >> l) & 1u) != 0u);
+        if (lane == 0) s_cnt[(3u + (uint32_t)l) * NW + wave] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {             // children: exclusive sums over (kind 0 waves..., kind 1 waves...)
+        uint32_t tot = 0;
+        for (uint32_t k = 0; k < 2u * NW; k++) { const uint32_t t = s_cnt[k]; s_cnt[k] = tot; tot += t; }
+        s_base[0] = tot ? atomicAdd(&A.cnt->next_count, tot) : 0u;
+    } else if (threadIdx.x == WAVE) {   // shadow rays, light by light (another wave: runs beside the first)
+        uint32_t tot = 0;
+        for (uint32_t k = 3u * NW; k < n_kinds * NW; k++) { const uint32_t t = s_cnt[k]; s_cnt[k] = tot; tot += t; }
+        s_base[1] = tot ? atomicAdd(&A.cnt->shq_count, tot) : 0u;
+    } else if (threadIdx.x == 2 * WAVE) {   // shaded nodes of this level (shadow rays = shaded nodes x lights)
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < NW; w++) tot += s_cnt[2 * NW + w];
+        if (tot) atomicAdd(&A.cnt->shaded, tot);
+    }
+    __syncthreads();
     int32_t slot_refl = -1, slot_refr = -1;
-    if (!A.last_level) {
-        // the refracted rays of the workgroup take one run of slots, the reflected ones the next: neighbours in the
-        // queue then are rays of one kind from neighbouring pixels, which walk the same part of the tree
-        uint32_t cs = block_reserve(want_refr ? 1u : 0u, &A.cnt->next_count, s_wave);
-        if (want_refr && cs < A.nxt_cap) {
+    if (want_refr) {
+        const uint32_t cs = s_base[0] + s_cnt[0 * NW + wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_refr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_refr, 0u));
+        if (cs < A.nxt_cap) {
             slot_refr = (int32_t)cs;
             store_ray(A.nxt.ray, cs, c_refr_o, c_refr_d);
         }
-        cs = block_reserve(want_refl ? 1u : 0u, &A.cnt->next_count, s_wave);
-        if (want_refl && cs < A.nxt_cap) {
+    }
+    if (want_refl) {
+        const uint32_t cs = s_base[0] + s_cnt[1 * NW + wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m_refl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_refl, 0u));
+        if (cs < A.nxt_cap) {
             slot_refl = (int32_t)cs;
             store_ray(A.nxt.ray, cs, c_refl_o, c_refl_d);
         }
-    }
-    {   // shaded nodes of this level (shadow rays = shaded nodes x lights)
-        const unsigned long long m = __ballot(hit);
-        if (threadIdx.x == 0) s_wave[0] = 0u;
-        __syncthreads();
-        if (m && lane_id() == 0) atomicAdd(&s_wave[0], (uint32_t)__popcll(m));
-        __syncthreads();
-        if (threadIdx.x == 0 && s_wave[0]) atomicAdd(&A.cnt->shaded, s_wave[0]);
-        __syncthreads();
     }
     if (hit) {
         A.cur.kr[tid] = kReflect; A.cur.kt[tid] = kRefract;
@@ -779,11 +797,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
             A.hit_ids[(size_t)py * A.g.W + px] = sf.hit_id;
         }
     }
-    // shadow rays that must walk the tree: one reservation per light for the whole workgroup, so that a run of the
-    // queue holds rays towards ONE light from neighbouring surface points (they cross the same cells)
+    // shadow rays that must walk the tree
     for (int l = 0; l < S.n_lights; l++) {
-        const bool mine = (kd_mask >> l) & 1u;
-        const uint32_t slot = block_reserve(mine ? 1u : 0u, &A.cnt->shq_count, s_wave);
+        const bool mine = ((kd_mask >> l) & 1u) != 0u;
+        const unsigned long long m = __ballot(mine);
+        const uint32_t slot = s_base[1] + s_cnt[(3u + (uint32_t)l) * NW + wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (mine && slot < A.shq_cap) {
             const V3 sd = shadow_dir(S, l, sf.point);
             float t0, t1;
