@@ -46,6 +46,7 @@ public:
               int64_t n_faces, int max_depth, double infinity, std::string &err);
 
     GpuKdTree tree;
+    int predicted_misses = 0;       // builds whose predicted sizes did not hold and that were repeated level by level
 
 private:
     struct LevelNodes {
@@ -54,7 +55,7 @@ private:
         uint32_t *heap = nullptr, *start = nullptr, *count = nullptr, *pos = nullptr;
     };
     int build_once(hipStream_t stream, const double *verts, int64_t n_verts, const uint32_t *faces, const int32_t *face_mat,
-                   int64_t n_faces, int max_depth, double infinity, std::string &err);   // 1 = a list ran out and was enlarged
+                   int64_t n_faces, int max_depth, double infinity, bool predicted, std::string &err);   // 1 = build again
     int reserve(int64_t n_verts, int64_t n_faces, std::string &err);
     int grow_pool = 1, grow_nodes = 1, grow_leaves = 1;
     int ensure_nodes(hipStream_t s, uint32_t slots, std::string &err);
@@ -78,6 +79,12 @@ private:
     uint32_t cap_leaves = 0, cap_pairs = 0;
     uint32_t *counters = nullptr;                            // device: leaves, pairs, empties, root box keys
     uint32_t *h_counters = nullptr;                          // pinned
+    uint32_t *lstate = nullptr, *h_lstate = nullptr;         // sizes of every level (device, pinned copy)
+    unsigned long long *h_total = nullptr;                   // pinned
+    // sizes of the last build: bounds of the next one when the mesh has the same number of faces
+    uint32_t hist_pool[26] = {}, hist_active[26] = {}, hist_leaves = 0, hist_used = 0;
+    int hist_levels = 0, hist_max_depth = 0;
+    int64_t hist_faces = -1;
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     uint32_t cap_node_slots = 0, cap_slots = 0, cap_tris = 0, cap_leaf_table = 0;

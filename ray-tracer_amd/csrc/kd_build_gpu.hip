@@ -30,6 +30,10 @@ constexpr uint32_t T_INTERNAL = 1u << 30, T_EMPTY = 2u << 30, T_LEAF = 3u << 30;
 constexpr uint32_t NONE = 0xffffffffu;
 constexpr uint32_t CODES = 1u << PATH_BITS;
 enum { C_LEAVES = 0, C_PAIRS = 1, C_EMPTY = 2, C_WORDS = 4 };
+// state of one level in device memory: what the level before it produced. The kernels of a level read their sizes
+// from here, so that the host can queue all levels without waiting for any of them (grids are sized by bounds).
+enum { ST_POOL = 0, ST_ACTIVE = 1, ST_BLOCK = 2, ST_USED = 3, ST_OVER = 4, ST_WORDS = 8 };
+constexpr int MAX_BUILD_LEVELS = 26;
 
 struct Nodes {
     double *blo, *bhi;
@@ -93,13 +97,18 @@ __device__ __forceinline__ uint32_t owner_of(const uint32_t *pool_owner, const u
 }
 
 __global__ __launch_bounds__(256) void k_kd_test(const double *verts, const uint32_t *faces, const uint32_t *pool_face,
-                                                 const uint32_t *pool_owner, const uint32_t *owner_map, uint32_t n_pool,
-                                                 Nodes cur, int axis, uint32_t *flags) {
+                                                 const uint32_t *pool_owner, const uint32_t *owner_map, const uint32_t *st,
+                                                 uint32_t bound, Nodes cur, int axis, uint32_t *flags) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n_pool) return;
-    const uint32_t o = owner_of(pool_owner, owner_map, p);
-    if (o == NONE) return;   // this face belongs to a leaf
+    if (p == 0u) flags[2 * (size_t)bound] = 0u;   // the last element of the scan: its exclusive sum is the total
+    if (p >= bound) return;
+    // The flags of an active node's list [start, start + cnt) fill [2 start, 2 start + 2 cnt). The same slice for the
+    // list of a leaf (and for the unused tail of the grid) is {2p, 2p + 1} of its entries: they are cleared here, so
+    // that the array needs no separate fill before the scan.
+    const uint32_t o = p < st[ST_POOL] ? owner_of(pool_owner, owner_map, p) : NONE;
+    if (o == NONE) { flags[2 * (size_t)p] = 0u; flags[2 * (size_t)p + 1] = 0u; return; }   // this face belongs to a leaf
     const uint32_t start = cur.start[o], cnt = cur.count[o], j = p - start;
+    if ((unsigned long long)start + cnt > st[ST_POOL] || j >= cnt) return;   // never for a consistent level: stay inside the lists
     double lo[3], hi[3];
     for (int k = 0; k < 3; k++) { lo[k] = cur.blo[3 * (size_t)o + k]; hi[k] = cur.bhi[3 * (size_t)o + k]; }
     const uint32_t *f = faces + 3 * (size_t)pool_face[p];
@@ -113,14 +122,15 @@ __global__ __launch_bounds__(256) void k_kd_test(const double *verts, const uint
     }
 }
 
-__global__ __launch_bounds__(256) void k_kd_scatter(const uint32_t *pool_face, const uint32_t *pool_owner, const uint32_t *owner_map,
-                                                    uint32_t n_pool, Nodes cur, const uint32_t *flags, const uint32_t *scanned,
-                                                    uint32_t next_cap, uint32_t *next_face, uint32_t *next_owner) {
-    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n_pool) return;
+__device__ __forceinline__ void kd_scatter(uint32_t block, const uint32_t *pool_face, const uint32_t *pool_owner, const uint32_t *owner_map,
+                                           const uint32_t *st, uint32_t bound, const Nodes &cur, const uint32_t *flags,
+                                           const uint32_t *scanned, uint32_t next_cap, uint32_t *next_face, uint32_t *next_owner) {
+    const uint32_t p = block * 256 + threadIdx.x;
+    if (p >= min(st[ST_POOL], bound)) return;
     const uint32_t o = owner_of(pool_owner, owner_map, p);
     if (o == NONE) return;
     const uint32_t start = cur.start[o], cnt = cur.count[o], j = p - start;
+    if ((unsigned long long)start + cnt > st[ST_POOL] || j >= cnt) return;
     for (uint32_t i = 0; i < 2; i++) {
         const size_t e = 2 * (size_t)start + (size_t)i * cnt + j;
         if (flags[e]) {
@@ -131,17 +141,62 @@ __global__ __launch_bounds__(256) void k_kd_scatter(const uint32_t *pool_face, c
 }
 
 // child c of active node o is child 2*o + c of the level
-__global__ __launch_bounds__(256) void k_kd_classify(Nodes cur, uint32_t n_active, const uint32_t *scanned, int child_depth,
-                                                     int max_depth, uint32_t *child_start, uint32_t *child_count, uint32_t *child_flag) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= 2 * n_active) return;
+__device__ __forceinline__ void kd_classify(uint32_t block, const Nodes &cur, const uint32_t *st, uint32_t bound, const uint32_t *scanned,
+                                            int child_depth, int max_depth, uint32_t *child_start, uint32_t *child_count,
+                                            uint32_t *child_flag) {
+    const uint32_t t = block * 256 + threadIdx.x;
+    if (t == 0u) child_flag[2 * (size_t)bound] = 0u;   // the last element of the scan
+    if (t >= 2 * bound) return;
+    if (t >= 2 * st[ST_ACTIVE]) { child_flag[t] = 0u; return; }
     const uint32_t o = t >> 1, c = t & 1u;
     const uint32_t start = cur.start[o], cnt = cur.count[o];
+    if ((unsigned long long)start + cnt > st[ST_POOL]) { child_start[t] = 0u; child_count[t] = 0u; child_flag[t] = 0u; return; }
     const size_t e0 = 2 * (size_t)start + (size_t)c * cnt;
     const uint32_t first = scanned[e0], n = scanned[e0 + cnt] - first;
     child_start[t] = first;
     child_count[t] = n;
     child_flag[t] = (n > 4u && child_depth < max_depth) ? 1u : 0u;   // js/8-kd_tree.js:1683
+}
+
+// what a level produced = the sizes of the next one. The children of the root and of every third level below it open
+// new 16-slot blocks. A list that would run out stops the build here (sizes 0) and is named in the flags.
+// both read the exclusive sums over the flags and nothing of each other: one launch, the first blocks scatter
+__global__ __launch_bounds__(256) void k_kd_scatter_classify(uint32_t scatter_blocks, const uint32_t *pool_face, const uint32_t *pool_owner,
+                                                             const uint32_t *owner_map, const uint32_t *st, uint32_t bound_pool,
+                                                             uint32_t bound_active, Nodes cur, const uint32_t *flags,
+                                                             const uint32_t *scanned, uint32_t next_cap, uint32_t *next_face,
+                                                             uint32_t *next_owner, int child_depth, int max_depth,
+                                                             uint32_t *child_start, uint32_t *child_count, uint32_t *child_flag) {
+    if (blockIdx.x < scatter_blocks)
+        kd_scatter(blockIdx.x, pool_face, pool_owner, owner_map, st, bound_pool, cur, flags, scanned, next_cap, next_face, next_owner);
+    else
+        kd_classify(blockIdx.x - scatter_blocks, cur, st, bound_active, scanned, child_depth, max_depth, child_start, child_count, child_flag);
+}
+
+struct Advance {
+    const uint32_t *pool_total, *active_total;   // the last elements of the two exclusive sums of the level
+    uint32_t bound_pool, bound_active, cap_pool, cap_nodes, node_cap;
+    int next_opens_block;
+};
+__device__ __forceinline__ void kd_advance(const Advance &a, const uint32_t *st, uint32_t *nxt) {
+    const uint32_t *pool_total = a.pool_total, *active_total = a.active_total;
+    const uint32_t bound_pool = a.bound_pool, bound_active = a.bound_active, cap_pool = a.cap_pool, cap_nodes = a.cap_nodes,
+                   node_cap = a.node_cap;
+    const int next_opens_block = a.next_opens_block;
+    uint32_t n_pool = *pool_total, n_active = *active_total, over = st[ST_OVER];
+    const uint32_t used = st[ST_USED];
+    // this level was larger than the grids it ran on: it was processed in part only, nothing may build on it
+    if (st[ST_POOL] > bound_pool || st[ST_ACTIVE] > bound_active) over |= 16u;
+    if (n_pool > cap_pool) over |= 1u;
+    if (n_active > cap_nodes) over |= 2u;
+    uint32_t used_next = used;
+    if (next_opens_block) {
+        if ((unsigned long long)used + 16ull * n_active > 0x0fffffffull) over |= 8u;
+        else used_next = used + 16u * n_active;
+    }
+    if (used_next > node_cap) over |= 4u;
+    if (over) n_pool = n_active = 0u;
+    nxt[ST_POOL] = n_pool; nxt[ST_ACTIVE] = n_active; nxt[ST_BLOCK] = used; nxt[ST_USED] = over ? used : used_next; nxt[ST_OVER] = over;
 }
 
 struct EmitOut {
@@ -154,12 +209,15 @@ struct EmitOut {
     uint32_t *counters;
 };
 
-__global__ __launch_bounds__(256) void k_kd_emit(Nodes cur, Nodes nxt, uint32_t n_active, uint32_t next_cap_nodes, int axis,
-                                                 int opens_block, uint32_t block_base, const uint32_t *child_start,
+__global__ __launch_bounds__(256) void k_kd_emit(Nodes cur, Nodes nxt, const uint32_t *st, uint32_t bound, uint32_t next_cap_nodes,
+                                                 int axis, int opens_block, const uint32_t *child_start,
                                                  const uint32_t *child_count, const uint32_t *child_flag, const uint32_t *child_scan,
-                                                 const uint32_t *next_face, uint32_t pool_cap, uint32_t *owner_map, EmitOut out) {
+                                                 const uint32_t *next_face, uint32_t pool_cap, uint32_t *owner_map, EmitOut out,
+                                                 Advance adv, uint32_t *st_next) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= 2 * n_active) return;
+    if (t == 0u) kd_advance(adv, st, st_next);   // the sizes of the next level (the sums of this one are complete)
+    if (t >= 2 * min(st[ST_ACTIVE], bound)) return;
+    const uint32_t block_base = st[ST_BLOCK];
     const uint32_t o = t >> 1, c = t & 1u;
     const uint32_t pos = cur.pos[o], heap = cur.heap[o];
     // treelet layout (kd_build.cpp: relayout_treelets): a 16-slot block holds a pair, its four children and eight
@@ -226,21 +284,21 @@ __device__ __forceinline__ uint32_t code_of_heap(uint32_t heap) {
 // prefix-free). code_count is indexed by the complement of the code, so that an exclusive sum over it runs in that order:
 // low word = faces kept by the leaves before this one (its first slot in the leaf-ordered triangle table), high word =
 // number of leaves before it (its index).
-__global__ __launch_bounds__(256) void k_kd_leaf_mark(const uint32_t *leaf_heap, const uint32_t *leaf_count, uint32_t n_leaves,
-                                                      unsigned long long *code_count) {
+__global__ __launch_bounds__(256) void k_kd_leaf_mark(const uint32_t *leaf_heap, const uint32_t *leaf_count, const uint32_t *n_leaves,
+                                                      uint32_t bound, unsigned long long *code_count) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_leaves) return;
+    if (i >= min(*n_leaves, bound)) return;
     const uint32_t key = ~code_of_heap(leaf_heap[i]) & (CODES - 1u);
     code_count[key] = (unsigned long long)leaf_count[i] | (1ull << 32);
 }
 
 __global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap, const uint32_t *leaf_count, const uint32_t *leaf_pos,
-                                                      const uint32_t *leaf_faces, uint32_t n_leaves,
-                                                      const unsigned long long *code_scan, const TriDev *tris, KdNodeDev *nodes,
+                                                      const uint32_t *leaf_faces, const uint32_t *n_leaves, uint32_t bound,
+                                                      const unsigned long long *code_scan, const TriDev *tris, uint32_t n_tris, KdNodeDev *nodes,
                                                       uint32_t node_cap, TriDev *ltris, uint32_t cap_slots, uint32_t *path_slot,
                                                       int32_t *leaves, uint2 *pairs, uint32_t cap_pairs, uint32_t *counters) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_leaves) return;
+    if (i >= min(*n_leaves, bound)) return;
     const uint32_t heap = leaf_heap[i], code = code_of_heap(heap), cnt = leaf_count[i];
     const unsigned long long x = code_scan[~code & (CODES - 1u)];
     const uint32_t first = (uint32_t)x, number = (uint32_t)(x >> 32);
@@ -249,7 +307,7 @@ __global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap,
     for (uint32_t k = 0; k < 4u; k++) {
         const uint32_t f = leaf_faces[4 * (size_t)i + k];
         leaves[4 * (size_t)number + k] = k < cnt ? (int32_t)f : -1;
-        if (k < cnt && first + k < cap_slots) {
+        if (k < cnt && first + k < cap_slots && f < n_tris) {
             TriDev t = tris[f];
             t.code = code;
             ltris[first + k] = t;
@@ -257,6 +315,22 @@ __global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap,
     }
     const uint32_t pi = atomicAdd(&counters[C_PAIRS], 1u);
     if (pi < cap_pairs) pairs[pi] = make_uint2(heap, T_LEAF | number);
+}
+
+__device__ __forceinline__ double device_key_value(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// level 0: the root owns every face, in index order; its children open the block behind the root's own 16-slot line
+__global__ void k_kd_init_root(const unsigned long long *box_keys, Nodes cur, uint32_t n_faces, uint32_t *st) {
+    for (int k = 0; k < 3; k++) {
+        const double lo = device_key_value(box_keys[k]), hi = device_key_value(box_keys[3 + k]);
+        cur.blo[k] = lo; cur.bhi[k] = hi;
+        cur.flo[k] = (float)lo; cur.fhi[k] = (float)hi;
+    }
+    cur.heap[0] = 0u; cur.start[0] = 0u; cur.count[0] = n_faces; cur.pos[0] = 0u;
+    st[ST_POOL] = n_faces; st[ST_ACTIVE] = 1u; st[ST_BLOCK] = 16u; st[ST_USED] = 32u; st[ST_OVER] = 0u;
 }
 
 #define KCK(call)                                                              \
@@ -285,7 +359,7 @@ GpuKdBuilder::~GpuKdBuilder() { release(); }
 void GpuKdBuilder::release() {
     void *ptrs[] = {d_verts, d_faces, d_face_mat, pool_face[0], pool_face[1], pool_owner[0], pool_owner[1], flags, scanned,
                     child_flag, child_scan, child_count, child_start, owner_map, code_count, code_scan, leaf_heap, leaf_count,
-                    leaf_pos, leaf_faces, counters, scan_tmp, tree.nodes, tree.tris, tree.ltris, tree.path_slot, tree.pairs,
+                    leaf_pos, leaf_faces, counters, lstate, scan_tmp, tree.nodes, tree.tris, tree.ltris, tree.path_slot, tree.pairs,
                     tree.leaves};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -293,6 +367,8 @@ void GpuKdBuilder::release() {
         for (void *p : {(void *)l.blo, (void *)l.bhi, (void *)l.flo, (void *)l.fhi, (void *)l.heap, (void *)l.start, (void *)l.count, (void *)l.pos})
             if (p) (void)hipFree(p);
     if (h_counters) (void)hipHostFree(h_counters);
+    if (h_lstate) (void)hipHostFree(h_lstate);
+    if (h_total) (void)hipHostFree(h_total);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
 }
@@ -303,6 +379,9 @@ int GpuKdBuilder::reserve(int64_t n_verts, int64_t n_faces, std::string &err) {
     if (!counters) {
         KCK(hipMalloc((void **)&counters, (C_WORDS + 12) * sizeof(uint32_t)));   // counters, then six 64-bit box keys
         KCK(hipHostMalloc((void **)&h_counters, (C_WORDS + 12) * sizeof(uint32_t)));
+        KCK(hipMalloc((void **)&lstate, (size_t)MAX_BUILD_LEVELS * ST_WORDS * sizeof(uint32_t)));
+        KCK(hipHostMalloc((void **)&h_lstate, (size_t)MAX_BUILD_LEVELS * ST_WORDS * sizeof(uint32_t)));
+        KCK(hipHostMalloc((void **)&h_total, sizeof(unsigned long long)));
     }
     if ((size_t)n_verts > cap_verts) { if (grow(d_verts, (size_t)n_verts * 3, err)) return -1; cap_verts = (size_t)n_verts; }
     if ((size_t)n_faces > cap_faces) {
@@ -381,147 +460,178 @@ int GpuKdBuilder::ensure_nodes(hipStream_t s, uint32_t slots, std::string &err) 
 
 // The lists are sized from the face count; a mesh whose faces spread over many more cells than usual asks for more:
 // the list that ran out is enlarged and the build starts over.
+//
+// Two ways through a build. The first build of a mesh waits for the sizes of every level (one small read-back per
+// level), because nothing is known about the tree. It leaves the sizes behind, and the next build of a mesh with the
+// same number of faces - the same mesh moved, which is what the reference rebuilds for (js/8-kd_tree.js:2494-2522) -
+// queues all levels at once over grids a quarter larger than last time's, with the true sizes read on the device;
+// one read-back at the end tells whether every bound held. If one did not, the build is repeated the first way.
 int GpuKdBuilder::build(hipStream_t s, const double *verts, int64_t n_verts, const uint32_t *faces, const int32_t *face_mat,
                         int64_t n_faces, int max_depth, double infinity, std::string &err) {
+    if (hist_levels > 0 && hist_faces == n_faces && hist_max_depth == max_depth && !getenv("RT_KD_BUILD_SYNC")) {
+        const int r = build_once(s, verts, n_verts, faces, face_mat, n_faces, max_depth, infinity, true, err);
+        if (r <= 0) return r;
+        predicted_misses++;
+    }
     for (int attempt = 0; attempt < 12; attempt++) {
-        const int r = build_once(s, verts, n_verts, faces, face_mat, n_faces, max_depth, infinity, err);
+        const int r = build_once(s, verts, n_verts, faces, face_mat, n_faces, max_depth, infinity, false, err);
         if (r <= 0) return r;
     }
     err = "device k-d build: lists still too small after repeated growth (" + err + ")";
     return -1;
 }
 
+// returns 0, -1 (error), 1 (a list ran out and was enlarged, or a predicted bound did not hold: build again)
 int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts, const uint32_t *faces, const int32_t *face_mat,
-                             int64_t n_faces, int max_depth, double infinity, std::string &err) {
+                             int64_t n_faces, int max_depth, double infinity, bool predicted, std::string &err) {
     if (max_depth > 24) max_depth = 24;
     if (n_faces <= 4 || max_depth <= 1) { err = "device k-d build needs more than four faces and a depth limit above 1"; return -1; }
     if (n_faces > 0x0fffffff) { err = "device k-d build: too many faces"; return -1; }
     if (reserve(n_verts, n_faces, err)) return -1;
     const uint32_t nf = (uint32_t)n_faces;
+    auto with_margin = [](uint32_t n, uint32_t extra, uint32_t cap) { return (uint32_t)std::min<uint64_t>((uint64_t)n + n / 4 + extra, cap); };
+    if (predicted && ensure_nodes(s, with_margin(hist_used, 4096, 0x0fffffffu), err)) return -1;
     KCK(hipMemcpyAsync(d_verts, verts, (size_t)n_verts * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     KCK(hipMemcpyAsync(d_faces, faces, (size_t)n_faces * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     KCK(hipMemcpyAsync(d_face_mat, face_mat, (size_t)n_faces * sizeof(int32_t), hipMemcpyHostToDevice, s));
     KCK(hipEventRecord(ev0, s));
 
-    // counters and the root box
+    // counters, the root box, level 0
     unsigned long long *box_keys = (unsigned long long *)(counters + C_WORDS);
-    {
-        memset(h_counters, 0, (C_WORDS + 12) * sizeof(uint32_t));
-        unsigned long long *hk = (unsigned long long *)(h_counters + C_WORDS);
-        for (int k = 0; k < 3; k++) { hk[k] = host_order_key(infinity); hk[3 + k] = host_order_key(-infinity); }
-        KCK(hipMemcpyAsync(counters, h_counters, (C_WORDS + 12) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_kd_root_box, blocks_for(nf), dim3(256), 0, s, d_verts, d_faces, nf, box_keys);
-        hipLaunchKernelGGL(k_kd_make_tris, blocks_for(nf), dim3(256), 0, s, d_verts, d_faces, d_face_mat, nf, tree.tris);
-        KCK(hipMemcpyAsync(h_counters, counters, (C_WORDS + 12) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        KCK(hipStreamSynchronize(s));
-        for (int k = 0; k < 6; k++) tree.root_box[k] = key_value(hk[k]);
-    }
-
-    // level 0: the root owns every face, in index order
+    unsigned long long *hk = (unsigned long long *)(h_counters + C_WORDS);
     Nodes cur{lv[0].blo, lv[0].bhi, lv[0].flo, lv[0].fhi, lv[0].heap, lv[0].start, lv[0].count, lv[0].pos};
     Nodes nxt{lv[1].blo, lv[1].bhi, lv[1].flo, lv[1].fhi, lv[1].heap, lv[1].start, lv[1].count, lv[1].pos};
-    {
-        double bd[6];
-        float bf[6];
-        for (int k = 0; k < 6; k++) { bd[k] = tree.root_box[k]; bf[k] = (float)tree.root_box[k]; }
-        const uint32_t zero = 0, cnt = nf;
-        KCK(hipMemcpyAsync(cur.blo, bd, 3 * sizeof(double), hipMemcpyHostToDevice, s));
-        KCK(hipMemcpyAsync(cur.bhi, bd + 3, 3 * sizeof(double), hipMemcpyHostToDevice, s));
-        KCK(hipMemcpyAsync(cur.flo, bf, 3 * sizeof(float), hipMemcpyHostToDevice, s));
-        KCK(hipMemcpyAsync(cur.fhi, bf + 3, 3 * sizeof(float), hipMemcpyHostToDevice, s));
-        KCK(hipMemcpyAsync(cur.heap, &zero, 4, hipMemcpyHostToDevice, s));
-        KCK(hipMemcpyAsync(cur.start, &zero, 4, hipMemcpyHostToDevice, s));
-        KCK(hipMemcpyAsync(cur.count, &cnt, 4, hipMemcpyHostToDevice, s));
-        KCK(hipMemcpyAsync(cur.pos, &zero, 4, hipMemcpyHostToDevice, s));
-        KCK(hipStreamSynchronize(s));   // the sources are locals
-        hipLaunchKernelGGL(k_kd_iota, blocks_for(nf), dim3(256), 0, s, pool_face[0], nf);
-        KCK(hipMemsetAsync(pool_owner[0], 0, (size_t)nf * sizeof(uint32_t), s));
+    memset(h_counters, 0, (C_WORDS + 12) * sizeof(uint32_t));
+    for (int k = 0; k < 3; k++) { hk[k] = host_order_key(infinity); hk[3 + k] = host_order_key(-infinity); }
+    KCK(hipMemcpyAsync(counters, h_counters, (C_WORDS + 12) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_kd_root_box, blocks_for(nf), dim3(256), 0, s, d_verts, d_faces, nf, box_keys);
+    hipLaunchKernelGGL(k_kd_make_tris, blocks_for(nf), dim3(256), 0, s, d_verts, d_faces, d_face_mat, nf, tree.tris);
+    hipLaunchKernelGGL(k_kd_init_root, dim3(1), dim3(1), 0, s, box_keys, cur, nf, lstate);
+    hipLaunchKernelGGL(k_kd_iota, blocks_for(nf), dim3(256), 0, s, pool_face[0], nf);
+    KCK(hipMemsetAsync(pool_owner[0], 0, (size_t)nf * sizeof(uint32_t), s));
+
+    uint32_t n_active = 1, n_pool = nf, used_slots = 32;   // (waiting build only) the root keeps a 16-slot line of its own
+    if (predicted) {
+        KCK(hipMemsetAsync(tree.nodes, 0, (size_t)cap_node_slots * sizeof(KdNodeDev), s));
+    } else {
+        if (ensure_nodes(s, used_slots, err)) return -1;
+        KCK(hipMemsetAsync(tree.nodes, 0, (size_t)used_slots * sizeof(KdNodeDev), s));
     }
-    uint32_t n_active = 1, n_pool = nf, used_slots = 16;   // the root keeps a 16-slot line of its own
-    if (ensure_nodes(s, used_slots, err)) return -1;
-    KCK(hipMemsetAsync(tree.nodes, 0, 16 * sizeof(KdNodeDev), s));
-    int side = 0;
-    tree.n_internal = 0;
-    tree.depth = 1;
+    int side = 0, levels = 0;
+    uint32_t grid_pool[MAX_BUILD_LEVELS], grid_active[MAX_BUILD_LEVELS];
     EmitOut out{tree.nodes, cap_node_slots, tree.pairs, cap_pairs, leaf_heap, leaf_count, leaf_pos, leaf_faces, cap_leaves, counters};
 
-    for (int d = 0; n_active > 0; d++) {   // d = depth of the active nodes, root = 0 (the reference counts from 1)
+    for (int d = 0; predicted ? d < hist_levels : n_active > 0; d++) {   // d = depth of the active nodes, root = 0 (the reference counts from 1)
+        if (d >= MAX_BUILD_LEVELS - 1) { err = "device k-d build: too many levels"; return -1; }
         const int axis = d % 3;            // js/8-kd_tree.js:1689-1702: x, y, z from the root down
-        const bool first_level = (d == 0);
-        const uint32_t *omap = first_level ? nullptr : owner_map;
-        const size_t n_flags = 2 * (size_t)n_pool + 1;
-        KCK(hipMemsetAsync(flags, 0, n_flags * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_kd_test, blocks_for(n_pool), dim3(256), 0, s, d_verts, d_faces, pool_face[side], pool_owner[side], omap,
-                           n_pool, cur, axis, flags);
+        const uint32_t *omap = d == 0 ? nullptr : owner_map;
+        const uint32_t gp = predicted ? with_margin(hist_pool[d], 4096, cap_pool) : n_pool;
+        const uint32_t ga = predicted ? with_margin(hist_active[d], 256, cap_level_nodes) : n_active;
+        grid_pool[d] = gp; grid_active[d] = ga;
+        uint32_t *st = lstate + (size_t)d * ST_WORDS;
+        const size_t n_flags = 2 * (size_t)gp + 1, n_child = 2 * (size_t)ga + 1;
+        hipLaunchKernelGGL(k_kd_test, blocks_for(gp), dim3(256), 0, s, d_verts, d_faces, pool_face[side], pool_owner[side], omap,
+                           st, gp, cur, axis, flags);
         size_t tmp = scan_tmp_bytes;
         KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, flags, scanned, (int)n_flags, s));
-        hipLaunchKernelGGL(k_kd_scatter, blocks_for(n_pool), dim3(256), 0, s, pool_face[side], pool_owner[side], omap, n_pool, cur,
-                           flags, scanned, cap_pool, pool_face[side ^ 1], pool_owner[side ^ 1]);
-        hipLaunchKernelGGL(k_kd_classify, blocks_for(2 * (uint64_t)n_active), dim3(256), 0, s, cur, n_active, scanned, d + 2, max_depth,
-                           child_start, child_count, child_flag);
-        const size_t n_child = 2 * (size_t)n_active + 1;
-        KCK(hipMemsetAsync(child_flag + 2 * (size_t)n_active, 0, sizeof(uint32_t), s));
+        const unsigned sb = blocks_for(gp).x;
+        hipLaunchKernelGGL(k_kd_scatter_classify, dim3(sb + blocks_for(2 * (uint64_t)ga).x), dim3(256), 0, s, sb, pool_face[side],
+                           pool_owner[side], omap, st, gp, ga, cur, flags, scanned, cap_pool, pool_face[side ^ 1], pool_owner[side ^ 1],
+                           d + 2, max_depth, child_start, child_count, child_flag);
         tmp = scan_tmp_bytes;
         KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, child_flag, child_scan, (int)n_child, s));
         // the children of the root and of every third level below it open new 16-slot blocks
         const bool opens_block = (d % 3 == 0);
-        uint32_t block_base = 0;
-        if (opens_block) {
-            block_base = used_slots;
-            if ((uint64_t)used_slots + 16ull * n_active > 0x0fffffffull) { err = "device k-d build: node array too large"; return -1; }
-            used_slots += 16u * n_active;
-            if (ensure_nodes(s, used_slots, err)) return -1;
-            KCK(hipMemsetAsync(tree.nodes + block_base, 0, (size_t)16 * n_active * sizeof(KdNodeDev), s));
-            out.nodes = tree.nodes;
-            out.node_cap = cap_node_slots;
-        }
         // the emit kernel writes owner_map, which k_kd_test / k_kd_scatter of this level read: they are done (same stream)
-        hipLaunchKernelGGL(k_kd_emit, blocks_for(2 * (uint64_t)n_active), dim3(256), 0, s, cur, nxt, n_active, cap_level_nodes, axis,
-                           opens_block ? 1 : 0, block_base, child_start, child_count, child_flag, child_scan, pool_face[side ^ 1],
-                           cap_pool, owner_map, out);
+        hipLaunchKernelGGL(k_kd_emit, blocks_for(2 * (uint64_t)ga), dim3(256), 0, s, cur, nxt, st, ga, cap_level_nodes, axis,
+                           opens_block ? 1 : 0, child_start, child_count, child_flag, child_scan, pool_face[side ^ 1],
+                           cap_pool, owner_map, out,
+                           Advance{scanned + 2 * (size_t)gp, child_scan + 2 * (size_t)ga, gp, ga, cap_pool, cap_level_nodes,
+                                   predicted ? cap_node_slots : 0xffffffffu, ((d + 1) % 3 == 0) ? 1 : 0},
+                           st + ST_WORDS);
         KCK(hipGetLastError());
-        uint32_t next_pool = 0, next_active = 0;
-        KCK(hipMemcpyAsync(&h_counters[C_WORDS + 12 - 2], scanned + 2 * (size_t)n_pool, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        KCK(hipMemcpyAsync(&h_counters[C_WORDS + 12 - 1], child_scan + 2 * (size_t)n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        KCK(hipStreamSynchronize(s));
-        next_pool = h_counters[C_WORDS + 12 - 2];
-        next_active = h_counters[C_WORDS + 12 - 1];
-        if (next_pool > cap_pool) { err = "face pool too small"; grow_pool *= 2; return 1; }
-        if (next_active > cap_level_nodes) { err = "level node arrays too small"; grow_nodes *= 2; return 1; }
-        tree.n_internal += n_active;
-        tree.depth = d + 2;
-        n_pool = next_pool;
-        n_active = next_active;
+        levels = d + 1;
+        if (!predicted) {
+            KCK(hipMemcpyAsync(h_lstate + (size_t)(d + 1) * ST_WORDS, st + ST_WORDS, ST_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            KCK(hipStreamSynchronize(s));
+            const uint32_t *hn = h_lstate + (size_t)(d + 1) * ST_WORDS;
+            if (hn[ST_OVER] & 1u) { err = "face pool too small"; grow_pool *= 2; return 1; }
+            if (hn[ST_OVER] & 2u) { err = "level node arrays too small"; grow_nodes *= 2; return 1; }
+            if (hn[ST_OVER] & 8u) { err = "device k-d build: node array too large"; return -1; }
+            hist_pool[d] = n_pool; hist_active[d] = n_active;
+            n_pool = hn[ST_POOL];
+            n_active = hn[ST_ACTIVE];
+            if (hn[ST_USED] > used_slots) {   // the blocks the next level's children will fill
+                const uint32_t before = used_slots;
+                used_slots = hn[ST_USED];
+                if (ensure_nodes(s, used_slots, err)) return -1;
+                KCK(hipMemsetAsync(tree.nodes + before, 0, (size_t)(used_slots - before) * sizeof(KdNodeDev), s));
+                out.nodes = tree.nodes;
+                out.node_cap = cap_node_slots;
+            }
+        }
         side ^= 1;
         std::swap(cur, nxt);
     }
 
     // leaves: numbering, leaf-ordered triangles, path table, reference leaf table
-    KCK(hipMemcpyAsync(h_counters, counters, C_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    KCK(hipStreamSynchronize(s));
-    const uint32_t n_leaves = h_counters[C_LEAVES];
-    if (n_leaves > cap_leaves) { err = "leaf list too small"; grow_leaves *= 2; return 1; }
+    uint32_t grid_leaves = 0;
+    if (predicted) {
+        grid_leaves = with_margin(hist_leaves, 1024, cap_leaves);
+    } else {
+        KCK(hipMemcpyAsync(h_counters, counters, C_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        KCK(hipStreamSynchronize(s));
+        grid_leaves = h_counters[C_LEAVES];
+        if (grid_leaves > cap_leaves) { err = "leaf list too small"; grow_leaves *= 2; return 1; }
+    }
     KCK(hipMemsetAsync(code_count, 0, ((size_t)CODES + 1) * sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_kd_leaf_mark, blocks_for(n_leaves), dim3(256), 0, s, leaf_heap, leaf_count, n_leaves, code_count);
+    hipLaunchKernelGGL(k_kd_leaf_mark, blocks_for(grid_leaves), dim3(256), 0, s, leaf_heap, leaf_count, counters + C_LEAVES, grid_leaves,
+                       code_count);
     size_t tmp = scan_tmp_bytes;
     KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, code_count, code_scan, (int)(CODES + 1), s));
-    hipLaunchKernelGGL(k_kd_leaf_emit, blocks_for(n_leaves), dim3(256), 0, s, leaf_heap, leaf_count, leaf_pos, leaf_faces, n_leaves,
-                       code_scan, tree.tris, tree.nodes, cap_node_slots, tree.ltris, cap_slots, tree.path_slot, tree.leaves, tree.pairs,
-                       cap_pairs, counters);
+    hipLaunchKernelGGL(k_kd_leaf_emit, blocks_for(grid_leaves), dim3(256), 0, s, leaf_heap, leaf_count, leaf_pos, leaf_faces,
+                       counters + C_LEAVES, grid_leaves, code_scan, tree.tris, nf, tree.nodes, cap_node_slots, tree.ltris, cap_slots,
+                       tree.path_slot, tree.leaves, tree.pairs, cap_pairs, counters);
     KCK(hipGetLastError());
-    unsigned long long total = 0;
-    KCK(hipMemcpyAsync(&total, code_scan + CODES, sizeof total, hipMemcpyDeviceToHost, s));
-    KCK(hipMemcpyAsync(h_counters, counters, C_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    KCK(hipMemcpyAsync(h_total, code_scan + CODES, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    KCK(hipMemcpyAsync(h_counters, counters, (C_WORDS + 12) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    KCK(hipMemcpyAsync(h_lstate, lstate, (size_t)(levels + 1) * ST_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     KCK(hipEventRecord(ev1, s));
     KCK(hipStreamSynchronize(s));
+    const uint32_t n_leaves = h_counters[C_LEAVES];
+    if (predicted) {
+        // did every bound hold? A level larger than its grid was only partly processed: everything after it is void
+        const uint32_t *last = h_lstate + (size_t)levels * ST_WORDS;
+        bool ok = last[ST_OVER] == 0u && last[ST_ACTIVE] == 0u && n_leaves <= grid_leaves;
+        for (int d = 0; d < levels && ok; d++) {
+            const uint32_t *hs = h_lstate + (size_t)d * ST_WORDS;
+            ok = hs[ST_POOL] <= grid_pool[d] && hs[ST_ACTIVE] <= grid_active[d];
+        }
+        if (!ok) { err = "a predicted size did not hold"; return 1; }
+    }
+    if (n_leaves > cap_leaves) { err = "leaf list too small"; grow_leaves *= 2; return 1; }
+    const unsigned long long total = *h_total;
     if ((uint32_t)(total >> 32) != n_leaves) { err = "device k-d build: two leaves share a path code"; return -1; }
     if (h_counters[C_PAIRS] > cap_pairs) { err = "node list too small"; grow_leaves *= 2; return 1; }
+    for (int k = 0; k < 6; k++) tree.root_box[k] = key_value(hk[k]);
+    tree.n_internal = 0;
+    int real_levels = 0;   // a tree that got shallower leaves the last predicted levels without nodes
+    for (int d = 0; d < levels; d++) {
+        const uint32_t *hs = h_lstate + (size_t)d * ST_WORDS;
+        tree.n_internal += hs[ST_ACTIVE];
+        hist_pool[d] = hs[ST_POOL]; hist_active[d] = hs[ST_ACTIVE];
+        if (hs[ST_ACTIVE] > 0u) real_levels = d + 1;
+    }
+    levels = real_levels;
+    tree.depth = levels + 1;
+    hist_levels = levels; hist_faces = n_faces; hist_max_depth = max_depth; hist_leaves = n_leaves;
+    hist_used = h_lstate[(size_t)levels * ST_WORDS + ST_USED];
     tree.n_slots = (uint32_t)total;
     tree.n_leaves = n_leaves;
     tree.n_leaf = n_leaves;
     tree.n_empty = h_counters[C_EMPTY];
     tree.n_nodes = h_counters[C_PAIRS];
-    tree.n_node_slots = used_slots;
+    tree.n_node_slots = hist_used;
     float ms = 0;
     KCK(hipEventElapsedTime(&ms, ev0, ev1));
     tree.build_ms = ms;

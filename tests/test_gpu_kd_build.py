@@ -29,6 +29,10 @@ def test_device_builder_bit_exact_against_reference(ply, gold):
     assert (int((types == 1).sum()), int((types == 3).sum()), int((types == 2).sum())) == (kd["n_internal"], kd["n_leaf"], kd["n_empty"])
     assert sha(leaves) == kd["sha256"]["leaves_i32"]
     assert sha(pairs) == kd["sha256"]["nodes_sparse_u32"]
+    # a second build of the same mesh queues all levels at once over the sizes the first one left behind
+    rt.buildKdTree(on_device=True)
+    pairs2, leaves2, box2 = rt.exportKdTree()
+    assert np.array_equal(pairs2, pairs) and np.array_equal(leaves2, leaves) and np.array_equal(box2, box)
     rt.close()
 
 
@@ -54,6 +58,36 @@ def test_device_builder_random_meshes_match_oracle():
     rt.buildKdTree(on_device=True)
     pairs, leaves, _ = rt.exportKdTree()
     assert pairs.tolist() == [[0, (3 << 30) | 0]] and leaves.tolist() == [[0, 1, 2, -1]]
+    rt.close()
+
+
+def test_device_builder_repeated_builds_with_predicted_sizes():
+    """Builds after the first one of a face count run without waiting for the sizes of the levels: the same mesh
+    again, the mesh moved, a mesh of the same face count whose tree has quite different level sizes (the prediction
+    fails and the build is repeated level by level), and back. Every tree must equal the oracle's."""
+    rng = np.random.default_rng(5)
+    n_faces = 3000
+
+    def spread():
+        v = rng.uniform(-50, 50, size=(n_faces * 2, 3))
+        f = rng.integers(0, len(v), size=(n_faces, 3)).astype(np.uint32)
+        v[f[:, 1]] = v[f[:, 0]] + rng.normal(0, 2.0, size=(n_faces, 3))
+        v[f[:, 2]] = v[f[:, 0]] + rng.normal(0, 2.0, size=(n_faces, 3))
+        return v, f
+
+    va, fa = spread()
+    vb, fb = spread()
+    vb = vb * np.array([0.02, 0.02, 0.02])          # nearly everything in one small cluster ...
+    vb[:40] = rng.uniform(-500, 500, size=(40, 3))   # ... inside a huge root box: much deeper, much smaller levels
+    rt = abi.RayTracerHIP(abi.default_config(64, 48))
+    for v, f in ((va, fa), (va, fa), (va + np.array([3.0, -2.0, 5.0]), fa), (vb, fb), (vb, fb), (va, fa)):
+        rt.setMesh(v, f, np.zeros((n_faces, 2), np.uint32))
+        rt.buildKdTree(on_device=True)
+        pairs, leaves, box = rt.exportKdTree()
+        op, ol, ob, _ = oracle.kd_build(v, f)
+        assert np.array_equal(ob, box)
+        assert np.array_equal(ol, leaves)
+        assert np.array_equal(op, pairs)
     rt.close()
 
 
