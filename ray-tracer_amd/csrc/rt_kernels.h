@@ -612,12 +612,14 @@ struct Surface {
 
 // Rebuilds what the shader holds in HitInfo after the closest-hit search from the compact hit record.
 // Re-running the winning analytic test reproduces its normal and object-space point bit for bit.
-__device__ __forceinline__ bool make_surface(const SceneDev &S, V3 ro, V3 rd, float t, uint32_t hp, int32_t face, Surface &sf) {
+// `known`: the winning triangle's record if the caller holds it already (same values as S.tris[face]; spares a gather).
+__device__ __forceinline__ bool make_surface(const SceneDev &S, V3 ro, V3 rd, float t, uint32_t hp, int32_t face, Surface &sf,
+                                             const TriDev *known = nullptr) {
     const uint32_t best = hp & 0xffffu, last = hp >> 16;
     if (face < 0 && best == 0xffffu) return false;
     sf.point = ro + rd * t;
     if (face >= 0) {
-        const TriDev &T = S.tris[face];
+        const TriDev &T = known ? *known : S.tris[face];
         sf.normal = normalize(cross(ld3(T.e1), ld3(T.e2)));
         // intersectTriangle never writes localHitPoint (js/8-kd_tree.js:954): the shader still holds the
         // object-space point of the last analytic test that succeeded for this ray (zero if none did)
@@ -662,6 +664,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
     // mesh hit of the closest-hit walk: it replaces the analytic hit only if strictly nearer (js/8-kd_tree.js:948-949)
     float ht = A.cur.ht[i];
     int32_t hf = A.cur.hf[i];
+    const TriDev *winner = nullptr;
     if (active) {
         const unsigned long long key = A.cur.best[i];
         if (key != ~0ull && __uint_as_float((uint32_t)(key >> 32)) < ht) {
@@ -669,12 +672,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
             const TriDev &T = S.ltris[S.path_slot[(kr >> 2) ^ near_upper_levels(rd)] + (kr & 3u)];
             hit_tri(T, S.tri_eps, ro, rd, ht);   // the winner's exact t (the key folds -0 onto +0)
             hf = T.face;
+            winner = &T;
             A.cur.ht[i] = ht;
             A.cur.hf[i] = hf;
         }
     }
     Surface sf;
-    const bool hit = active && make_surface(S, ro, rd, ht, hp, hf, sf);
+    const bool hit = active && make_surface(S, ro, rd, ht, hp, hf, sf, winner);
     if (in_range && !hit) {
         V3 c = active ? ld3(S.bg) : v3(0, 0, 0);
         A.cur.cr[tid] = c.x; A.cur.cg[tid] = c.y; A.cur.cb[tid] = c.z;

@@ -105,6 +105,16 @@ def test_ragged_frame_and_supersampling():
     assert np.array_equal(rt2.present(), oracle.OracleRenderer(flat).present(g8, wl, ws))
 
 
+def test_odd_frame_rays_with_zero_direction_components():
+    """An odd width and height put a pixel centre exactly on the camera axis: the rays of the middle column have
+    direction x == 0, those of the middle row y == 0 (the corner rays are symmetric). Their plane distances on that axis
+    are infinite or NaN (js/8-kd_tree.js:888-930 divides by the component); the walk must take the same branches as the
+    shader, and such rays never hand stretches to idle lanes."""
+    flat = make_flat("bun_zipper_res3.ply", 321, 241, depth=3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    rt, o, (gf, g8, gid), cn = check_against_oracle(flat)
+    assert rt.stats().rays_total == cn.rays
+
+
 def test_kdtree_export_through_gpu_context():
     m = manifest("k8_res3_640x480")
     flat = make_flat("bun_zipper_res3.ply", 64, 48)
