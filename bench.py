@@ -19,6 +19,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Every frame in flight owns a HIP stream. The runtime maps streams onto 4 hardware queues by default, and two streams
+# that share a queue run their kernels one after the other: with 4 frames in flight a 1/8 shard took 2.23 ms per frame
+# against 1.99 ms with 3. Sixteen queues let a shard keep up to twelve frames in flight (1.75 ms). Read by the HIP
+# runtime when it starts, so it is set before anything touches the GPU (RT_HW_QUEUES overrides the number; the
+# environment's own GPU_MAX_HW_QUEUES usually just restates the default of 4).
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 
@@ -100,7 +106,8 @@ def main():
     ap.add_argument("--emulate-shards", type=int, default=0, help="single rank only: trace shard 0 of N (what one GPU of an N-GPU job does, without the exchange)")
     ap.add_argument("--emulate-index", type=int, default=0, help="with --emulate-shards: which shard to trace")
     ap.add_argument("--parts", type=int, default=0, help="concurrent slices per GPU (0 = library default)")
-    ap.add_argument("--in-flight", type=int, default=3, help="frames in flight per GPU (contexts that alternate frames); 1 = finish every frame before the next")
+    ap.add_argument("--in-flight", type=int, default=0, help="frames in flight per GPU (contexts that alternate frames); 1 = finish every frame before the next; "
+                                                             "0 = 3 for a whole frame per GPU, 6 / 8 / 12 for a half / a quarter / an eighth of it (a small shard leaves the GPU room for more)")
     ap.add_argument("--walk-waves", type=int, default=0, help="persistent walk waves per CU and context (0 = 24, 20 when tiles are exchanged between GPUs)")
     ap.add_argument("--sync-job", action="store_true", help="the host-synchronised frame job (every stage of the exchange waits on the host)")
     ap.add_argument("--kd-builder", default="host", choices=["host", "device"], help="where the k-d tree is built (same tree; the node blocks are laid out in a different order)")
@@ -144,7 +151,8 @@ def main():
                              device=local, parts=args.parts)
     flat = abi.FlatScene(sc, cfg, scene.camera_rays(args.width, args.height))
     pipelined = not args.sync_job and (world == 1 or by_frames or args.backend == "nccl")
-    n_ctx = max(1, args.in_flight) if pipelined else 1
+    in_flight = args.in_flight if args.in_flight > 0 else (3 if shard_count <= 1 else 6 if shard_count == 2 else 8 if shard_count <= 4 else 12)
+    n_ctx = in_flight if pipelined else 1
     t0 = time.perf_counter()
     rts = []
     for _ in range(n_ctx):
