@@ -63,12 +63,11 @@ struct FrameGeom {
 // counters do not queue behind each other in one L2 channel
 struct LevelCounters {
     uint32_t kdq_count, pad0[31];
-    uint32_t kdq_head, pad1[31];
     uint32_t shq_count, pad2[31];
-    uint32_t shq_head, pad3[31];
     uint32_t next_count, pad4[31];
     uint32_t shaded, pad5[31];
     uint32_t rec_count[2], pad6[30];      // leaf records tested by the closest / shadow walk (statistics)
+    uint32_t xq[2][8][32];                // per job and eighth of the queue: cursor (one per 128-byte line)
     unsigned long long walk_iters[2], walk_visits[2], walk_t0[2], walk_t1[2], walk_tsum[2], pad7[6];   // RT_WALK_STATS builds only: wave iterations, lane node visits, first start / last end / summed lifetime of the waves (100 MHz ticks)
 };
 
@@ -359,12 +358,33 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
                                          uint32_t *hit_flag, const uint32_t lane) {
     const KdNodeDev *__restrict__ nodes = S.nodes;
     const uint32_t total = ANY ? min(J.cnt->shq_count, J.q_cap) : J.cnt->kdq_count;
-    uint32_t *head = ANY ? &J.cnt->shq_head : &J.cnt->kdq_head;
+    // The queue is cut into eight contiguous parts, one per XCD (workgroups go round the XCDs by index): the waves of
+    // an XCD take the chunks of their own part first, so that each L2 sees the rays of one region of the image, and
+    // move on to the other parts when theirs is dry.
+    const uint32_t part_len = (((total + 7u) >> 3) + (uint32_t)REFILL_CHUNK - 1u) & ~((uint32_t)REFILL_CHUNK - 1u);
+    uint32_t part = blockIdx.x & 7u, parts_seen = 0u;
+    uint32_t part_begin = min(part * part_len, total), part_end = min(part_begin + part_len, total);
+    uint32_t *head = &J.cnt->xq[ANY ? 1 : 0][part][0];
+    // a part with no more chunks than its own XCD has waves is taken in one go by those: nobody else needs to ask
+    const uint32_t home_waves = gridDim.x >> 3;
+#define XQ_NEXT_PART()                                                                                          \
+    do {                                                                                                        \
+        last_chunk = 0u;                                                                                        \
+        for (;;) {                                                                                              \
+            parts_seen++;                                                                                       \
+            if (parts_seen >= 8u) { more = 0u; break; }                                                         \
+            part = (part + 1u) & 7u;                                                                            \
+            part_begin = min(part * part_len, total);                                                           \
+            part_end = min(part_begin + part_len, total);                                                       \
+            head = &J.cnt->xq[ANY ? 1 : 0][part][0];                                                            \
+            if (part_end - part_begin > home_waves * (uint32_t)REFILL_CHUNK) break;                             \
+        }                                                                                                       \
+    } while (0)
     const KdNodeDev root = nodes[0];
 
-    // wave-uniform: the global queue may still hold rays for this wave. There are ceil(total / chunk) chunks, so at
-    // most that many waves can ever get one: the waves beyond that number skip the job without touching the cursor
-    uint32_t more = blockIdx.x < (total + (uint32_t)REFILL_CHUNK - 1u) / (uint32_t)REFILL_CHUNK ? 1u : 0u;
+    // wave-uniform: the queue may still hold rays for this wave. A part has ceil(length / chunk) chunks, so at most that
+    // many waves of its XCD can ever get one: the waves beyond that number skip the job without touching a cursor
+    uint32_t more = (blockIdx.x >> 3) * (uint32_t)REFILL_CHUNK < part_end - part_begin ? 1u : 0u;
     uint32_t last_chunk = 0u;                // wave-uniform: the wave's chunk is the last of the queue
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
     float tmin = 0.0f, tmax = 0.0f, maxDist = 0.0f;
@@ -458,31 +478,34 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
                     q = chunk_pos + rank;
                     chunk_pos += n_idle;
                 } else if (UNIFORM(last_chunk)) {
-                    // the wave holds the end of the queue: what is left goes out, and no atomic is needed to know
-                    // that nothing follows
+                    // the wave holds the end of this part of the queue: what is left goes out, and no atomic is needed
+                    // to know that nothing follows in it
                     if (rank < left) q = chunk_pos + rank;
                     chunk_pos = chunk_end;
-                    more = 0u;
+                    XQ_NEXT_PART();
                 } else {
                     // the rays left in the old chunk are taken first, the rest comes from a new chunk.
                     // Atomics on one address are served one at a time (about 10 ns each), so the ones that can only
-                    // fail are avoided: a wave whose index is beyond the number of chunks never asks (see `more`
-                    // above), and the wave that got the last chunk knows it. (A device-scope load of the cursor
+                    // fail are avoided: a wave whose index in its XCD is beyond the number of chunks of the XCD's part
+                    // never asks (see `more` above), the wave that got the last chunk of a part knows it, and a part that
+                    // its own XCD empties in one go is not visited by the others. (A device-scope load of the cursor
                     // before the atomic instead measured twice as slow for the whole walk.)
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(head, (uint32_t)REFILL_CHUNK);
                     base = UNIFORM(base);
-                    if (base >= total) {
+                    base += part_begin;
+                    const uint32_t qend = part_end;
+                    if (base >= qend) {
                         if (rank < left) q = chunk_pos + rank;
                         chunk_pos = chunk_end = 0u;
-                        more = 0u;
+                        XQ_NEXT_PART();
                     } else {
-                        const uint32_t end = min(base + (uint32_t)REFILL_CHUNK, total);
+                        const uint32_t end = min(base + (uint32_t)REFILL_CHUNK, qend);
                         const uint32_t fresh = base + (rank - left);   // lanes served from the old chunk: unused
                         q = rank < left ? chunk_pos + rank : (fresh < end ? fresh : 0xffffffffu);
                         chunk_pos = min(base + (n_idle - left), end);
                         chunk_end = end;
-                        last_chunk = base + (uint32_t)REFILL_CHUNK >= total ? 1u : 0u;
+                        last_chunk = base + (uint32_t)REFILL_CHUNK >= qend ? 1u : 0u;
                     }
                 }
                 if (is_idle && q != 0xffffffffu) {
