@@ -275,14 +275,14 @@ static_assert(RT_REFILL_CHUNK >= 64, "REFILL_CHUNK must be at least the wave siz
 constexpr int REFILL_CHUNK = RT_REFILL_CHUNK;        // rays a wave reserves from the global queue per atomic
 constexpr int SHORT_STACK = RT_SHORT_STACK;          // power of two
 #ifndef RT_MAIL_SLOTS
-#define RT_MAIL_SLOTS 32
+#define RT_MAIL_SLOTS 16
 #endif
 constexpr int MAIL_SLOTS = RT_MAIL_SLOTS;                      // stretches that change hands in one exchange of a wave
 // leaf records waiting for their triangle tests: lane << 26 | the low 26 bits of the leaf's info ((faces - 1) << 24 | first slot in S.ltris).
 // The ring never holds more than 63 records when the lanes take their next actions.
 constexpr int TEST_RING = 256;
 #ifndef RT_WALK_ACTIONS
-#define RT_WALK_ACTIONS 2
+#define RT_WALK_ACTIONS 3
 #endif
 // tree actions per lane between two looks at the ring and at the number of idle lanes (the look costs about a sixth of
 // an action); a look finds at most 63 records left over and WALK_ACTIONS * 64 new ones
