@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,30 @@ using namespace rt;
 namespace {
 
 thread_local std::string g_create_error;
+
+// Device form of a k-d tree (nodes, leaf-ordered triangles, path table), shared by every context of the process that
+// uploads the same tree to the same GPU: a pipeline keeps several contexts with the same scene in flight, and their
+// walks run side by side - one copy keeps the L2 caches for one tree instead of one per context. Immutable once
+// registered; the last context to let go frees it.
+struct SharedTree {
+    int device = 0;
+    unsigned long long hash = 0;
+    size_t n_nodes = 0, n_ltris = 0;
+    KdNodeDev *nodes = nullptr;
+    TriDev *ltris = nullptr;
+    uint32_t *path_slot = nullptr;
+    int refs = 0;
+};
+std::mutex g_shared_mu;
+std::vector<SharedTree *> g_shared;
+
+unsigned long long fnv1a(const void *data, size_t n, unsigned long long h = 1469598103934665603ull) {
+    const unsigned long long *p = (const unsigned long long *)data;   // eight bytes a step: these are megabytes
+    for (size_t i = 0; i < n / 8; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    const unsigned char *q = (const unsigned char *)data + (n / 8) * 8;
+    for (size_t i = 0; i < n % 8; i++) { h ^= q[i]; h *= 1099511628211ull; }
+    return h;
+}
 
 // Pipeline step k of a frame: k_gen_prims(level k), k_kd_walk (closest-hit rays of level k together with the shadow
 // rays of level k-1, triangle tests included), k_shade_b(level k-1), k_shade_a(level k). A frame of depth D takes D+1
@@ -100,8 +125,9 @@ struct rt_ctx {
     TriDev *d_ltris = nullptr;
     uint2 *d_path_first = nullptr;               // staging of (path code, first slot) pairs
     uint32_t *d_path_slot = nullptr;             // 2^PATH_BITS entries, SceneDev::path_slot
+    SharedTree *shared = nullptr;                // d_nodes, d_ltris and d_path_slot belong to this shared copy, not to the context
     bool tree_dirty = true;
-    size_t cap_prims = 0, cap_mats = 0, cap_lights = 0, cap_tris = 0, cap_nodes = 0, cap_ltris = 0, cap_path_first = 0;
+    size_t cap_prims = 0, cap_mats = 0, cap_lights = 0, cap_tris = 0, cap_path_first = 0;
     // frame
     FrameGeom g{};                               // the whole shard
     uint32_t n0 = 0;                             // level-0 entries = tiles of this shard * 64
@@ -199,6 +225,22 @@ int ensure_level(rt_ctx *ctx, Part &P, int l, uint32_t cap) {
 constexpr uint32_t MAX_LEVEL_RAYS = 1u << 27;
 
 // traversal queues are shared by all levels: sized for the largest level seen so far
+// lets go of a shared tree copy; the context's pointers are cleared, so that nothing of it is freed or resized through them
+void detach_shared_tree(rt_ctx *ctx) {
+    if (!ctx->shared) return;
+    std::lock_guard<std::mutex> lock(g_shared_mu);
+    SharedTree *t = ctx->shared;
+    if (--t->refs == 0) {
+        (void)hipFree(t->nodes);
+        (void)hipFree(t->ltris);
+        (void)hipFree(t->path_slot);
+        g_shared.erase(std::remove(g_shared.begin(), g_shared.end(), t), g_shared.end());
+        delete t;
+    }
+    ctx->shared = nullptr;
+    ctx->d_nodes = nullptr; ctx->d_ltris = nullptr; ctx->d_path_slot = nullptr;
+}
+
 int ensure_queues(rt_ctx *ctx, Part &P, int level, uint32_t n_rays, uint32_t n_lights) {
     if (n_rays > MAX_LEVEL_RAYS) return fail(ctx, "rt_trace: a ray-tree level of more than 2^27 rays per part (raise rt_config.parts or shard the frame)");
     if (ensure(ctx, P.d_kdq, P.cap_kdq, n_rays)) return -1;
@@ -329,19 +371,49 @@ int upload_scene(rt_ctx *ctx) {
                 path_first.push_back(make_uint2(code, first[li]));
             }
         }
-        if (ensure(ctx, ctx->d_nodes, ctx->cap_nodes, nodes.size())) return -1;
-        if (ensure(ctx, ctx->d_ltris, ctx->cap_ltris, ltris.size())) return -1;
-        if (ensure(ctx, ctx->d_path_first, ctx->cap_path_first, path_first.size())) return -1;
-        if (!ctx->d_path_slot) HIPCK(hipMalloc((void **)&ctx->d_path_slot, sizeof(uint32_t) << PATH_BITS));
-        HIPCK(hipMemcpyAsync(ctx->d_nodes, nodes.data(), nodes.size() * sizeof(KdNodeDev), hipMemcpyHostToDevice, ctx->stream));
-        if (!ltris.empty()) HIPCK(hipMemcpyAsync(ctx->d_ltris, ltris.data(), ltris.size() * sizeof(TriDev), hipMemcpyHostToDevice, ctx->stream));
-        if (!path_first.empty()) {
-            // only the entries of existing leaves are ever read, so the table is not cleared
-            HIPCK(hipMemcpyAsync(ctx->d_path_first, path_first.data(), path_first.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_fill_path_slots, dim3((unsigned)((path_first.size() + 255) / 256)), dim3(256), 0, ctx->stream,
-                               ctx->d_path_first, (uint32_t)path_first.size(), ctx->d_path_slot);
-            HIPCK(hipGetLastError());
+        detach_shared_tree(ctx);
+        unsigned long long hash = fnv1a(nodes.data(), nodes.size() * sizeof(KdNodeDev));
+        hash = fnv1a(ltris.data(), ltris.size() * sizeof(TriDev), hash);
+        {   // another context of this process may hold this very tree on this GPU already
+            std::lock_guard<std::mutex> lock(g_shared_mu);
+            for (SharedTree *t : g_shared)
+                if (t->device == ctx->cfg.device && t->hash == hash && t->n_nodes == nodes.size() && t->n_ltris == ltris.size()) {
+                    t->refs++;
+                    ctx->shared = t;
+                    break;
+                }
         }
+        if (!ctx->shared) {
+            SharedTree *t = new SharedTree();
+            t->device = ctx->cfg.device; t->hash = hash; t->n_nodes = nodes.size(); t->n_ltris = ltris.size(); t->refs = 1;
+            auto drop = [&]() { (void)hipFree(t->nodes); (void)hipFree(t->ltris); (void)hipFree(t->path_slot); delete t; };
+            hipError_t e;
+            if ((e = hipMalloc((void **)&t->nodes, std::max<size_t>(nodes.size(), 1) * sizeof(KdNodeDev))) != hipSuccess ||
+                (e = hipMalloc((void **)&t->ltris, std::max<size_t>(ltris.size(), 1) * sizeof(TriDev))) != hipSuccess ||
+                (e = hipMalloc((void **)&t->path_slot, sizeof(uint32_t) << PATH_BITS)) != hipSuccess) {
+                drop();
+                return fail(ctx, (std::string("hipMalloc (k-d tree): ") + hipGetErrorString(e)).c_str());
+            }
+            if (ensure(ctx, ctx->d_path_first, ctx->cap_path_first, path_first.size())) { drop(); return -1; }
+            e = hipMemcpyAsync(t->nodes, nodes.data(), nodes.size() * sizeof(KdNodeDev), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess && !ltris.empty())
+                e = hipMemcpyAsync(t->ltris, ltris.data(), ltris.size() * sizeof(TriDev), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess && !path_first.empty()) {
+                // only the entries of existing leaves are ever read, so the table is not cleared
+                e = hipMemcpyAsync(ctx->d_path_first, path_first.data(), path_first.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(k_fill_path_slots, dim3((unsigned)((path_first.size() + 255) / 256)), dim3(256), 0, ctx->stream,
+                                       ctx->d_path_first, (uint32_t)path_first.size(), t->path_slot);
+                    e = hipGetLastError();
+                }
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the sources are locals; the copy is complete before anyone shares it
+            if (e != hipSuccess) { drop(); return fail(ctx, (std::string("k-d tree upload: ") + hipGetErrorString(e)).c_str()); }
+            std::lock_guard<std::mutex> lock(g_shared_mu);
+            g_shared.push_back(t);
+            ctx->shared = t;
+        }
+        ctx->d_nodes = ctx->shared->nodes; ctx->d_ltris = ctx->shared->ltris; ctx->d_path_slot = ctx->shared->path_slot;
         HIPCK(hipStreamSynchronize(ctx->stream));
         ctx->st.kd_upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         ctx->tree_dirty = false;
@@ -515,8 +587,9 @@ void rt_destroy(rt_ctx *ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     (void)hipDeviceSynchronize();
     delete ctx->gpu_kd;
-    void *ptrs[] = {ctx->d_scene, ctx->d_prims, ctx->d_mats, ctx->d_lights, ctx->d_tris, ctx->d_nodes, ctx->d_ltris,
-                    ctx->d_path_first, ctx->d_path_slot, ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_canvas,
+    detach_shared_tree(ctx);
+    void *ptrs[] = {ctx->d_scene, ctx->d_prims, ctx->d_mats, ctx->d_lights, ctx->d_tris,
+                    ctx->d_path_first, ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_canvas,
                     ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt,
                     ctx->d_tone_pair, ctx->d_tone, ctx->d_tone_d};
     for (void *p : ptrs)
