@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--emulate-shards", type=int, default=0, help="single rank only: trace shard 0 of N (what one GPU of an N-GPU job does, without the exchange)")
     ap.add_argument("--emulate-index", type=int, default=0, help="with --emulate-shards: which shard to trace")
+    ap.add_argument("--emulate-role", default="root", choices=["root", "worker", "whole"],
+                    help="with --emulate-shards: the device work of rank 0 of such a job (own tiles + scatter of the gathered canvas), of any other rank "
+                         "(own tiles only), or the shard's trace followed by a present pass over the whole frame")
     ap.add_argument("--parts", type=int, default=0, help="concurrent slices per GPU (0 = library default)")
     ap.add_argument("--in-flight", type=int, default=0, help="frames in flight per GPU (contexts that alternate frames); 1 = finish every frame before the next; "
                                                              "0 = 3 for a whole frame per GPU, 6 / 8 / 12 for a half / a quarter / an eighth of it (a small shard leaves the GPU room for more)")
@@ -174,7 +177,8 @@ def main():
         try:
             if os.environ.get("RT_BENCH_FAIL_PIPELINE"):   # test hook for the fall-back below
                 raise RuntimeError("RT_BENCH_FAIL_PIPELINE is set")
-            frame = multi_gpu.PipelinedFrameJob(rts, job_comm)
+            rehearse = (args.emulate_role, shard_count) if (world == 1 and shard_count > 1 and args.emulate_role != "whole") else None
+            frame = multi_gpu.PipelinedFrameJob(rts, job_comm, rehearse=rehearse)
             frame.step()
             frame.flush()
             torch.cuda.synchronize()

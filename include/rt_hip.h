@@ -230,6 +230,17 @@ int rt_device_shard_rgba8(rt_ctx *ctx, void **dptr, size_t *bytes);
  * the whole image. The scatter is queued on the context's stream (the rt_read_* calls and rt_present follow it in
  * stream order). Replaces nothing in the reference (single GPU there). */
 int rt_assemble_shards(rt_ctx *ctx, const void *gathered, size_t stride_bytes, int32_t n_shards);
+/* The present pass (js/8-kd_tree.js:85-143) spread over the ranks, SUPERSAMPLING 1 only (the shader then reads exactly
+ * its own pixel of the render target, so a shard's tiles can be finished where they were traced; with more it samples
+ * across tiles and these calls fail: present the assembled frame on the root instead). After the tone values are set
+ * (rt_tone_finish / rt_tone_finish_device), rt_present_shard runs the tone operator over this context's compact tiles
+ * (queued on its stream); rt_device_shard_canvas hands out the result in the layout of rt_device_shard_rgba8; on the
+ * root, rt_assemble_shards_canvas scatters the gathered canvas tiles into the canvas (rt_device_canvas) the way
+ * rt_assemble_shards fills the render target. The root then holds the finished canvas but only its own tiles of the
+ * render target. Replaces nothing in the reference (single GPU there). */
+int rt_present_shard(rt_ctx *ctx);
+int rt_device_shard_canvas(rt_ctx *ctx, void **dptr, size_t *bytes);
+int rt_assemble_shards_canvas(rt_ctx *ctx, const void *gathered, size_t stride_bytes, int32_t n_shards);
 /* The HIP stream (hipStream_t) on which this context queues its work. Work a caller queues on it - a collective, a
  * copy - is ordered with the library's kernels without any host synchronisation. No counterpart in the reference. */
 int rt_stream(rt_ctx *ctx, void **stream);

@@ -156,6 +156,9 @@ def lib():
         L.rt_device_canvas.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.rt_device_shard_rgba8.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.rt_assemble_shards.argtypes = [vp, vp, C.c_size_t, i32]
+        L.rt_assemble_shards_canvas.argtypes = [vp, vp, C.c_size_t, i32]
+        L.rt_present_shard.argtypes = [vp]
+        L.rt_device_shard_canvas.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.rt_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.rt_tone_partial_device.argtypes = [vp, C.POINTER(vp)]
         L.rt_tone_finish_device.argtypes = [vp, vp]
@@ -311,6 +314,10 @@ class RayTracerHIP:
         Lbar, sf = C.c_double(), C.c_double()
         self._ck(self.L.rt_tone_get(self.ctx, C.byref(Lbar), C.byref(sf)), "rt_tone_get")
         return Lbar.value, sf.value
+
+    def presentShard(self):
+        """The present pass over this shard's own tiles (supersampling 1), queued on the context's stream."""
+        self._ck(self.L.rt_present_shard(self.ctx), "rt_present_shard")
 
     def presentQueued(self):
         self._ck(self.L.rt_present(self.ctx, None), "rt_present")

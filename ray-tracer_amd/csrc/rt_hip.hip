@@ -133,6 +133,7 @@ struct rt_ctx {
     uint32_t n0 = 0;                             // level-0 entries = tiles of this shard * 64
     float *d_fb = nullptr;
     uint32_t *d_rgba = nullptr, *d_compact = nullptr, *d_canvas = nullptr;
+    uint32_t *d_compact_canvas = nullptr;        // rt_present_shard: the shard's tiles after the present pass
     int32_t *d_hit = nullptr;
     double *d_part_sum = nullptr, *d_tone_out = nullptr;
     double *d_tone_pair = nullptr;               // {sum of log luminance, pixel count} of this shard, for a device-side all-reduce
@@ -568,6 +569,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     ALLOC(ctx->d_hit, npx * 4);
     if ((e = hipMemset(ctx->d_hit, 0xff, npx * 4)) != hipSuccess) return bail("hipMemset", e);   // -1: pixels of other shards are never written
     ALLOC(ctx->d_compact, std::max<size_t>(ctx->n0, 64) * 4);
+    ALLOC(ctx->d_compact_canvas, std::max<size_t>(ctx->n0, 64) * 4);
     ALLOC(ctx->d_canvas, (size_t)cfg->width * cfg->height * 4);
     ALLOC(ctx->d_part_sum, TONE_BLOCKS * sizeof(double));
     ALLOC(ctx->d_part_cnt, TONE_BLOCKS * sizeof(unsigned long long));
@@ -589,7 +591,7 @@ void rt_destroy(rt_ctx *ctx) {
     delete ctx->gpu_kd;
     detach_shared_tree(ctx);
     void *ptrs[] = {ctx->d_scene, ctx->d_prims, ctx->d_mats, ctx->d_lights, ctx->d_tris,
-                    ctx->d_path_first, ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_canvas,
+                    ctx->d_path_first, ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_compact_canvas, ctx->d_canvas,
                     ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt,
                     ctx->d_tone_pair, ctx->d_tone, ctx->d_tone_d};
     for (void *p : ptrs)
@@ -1251,17 +1253,50 @@ int rt_device_shard_rgba8(rt_ctx *ctx, void **dptr, size_t *bytes) {
     return 0;
 }
 
-int rt_assemble_shards(rt_ctx *ctx, const void *gathered, size_t stride_bytes, int32_t n_shards) {
+static int assemble_into(rt_ctx *ctx, const char *who, const void *gathered, size_t stride_bytes, int32_t n_shards, uint32_t *target) {
     if (!ctx) return -1;
-    if (ctx->host_only) return fail(ctx, "rt_assemble_shards: host-only context (created with device = -1)");
-    if (!gathered || n_shards < 1 || stride_bytes % 256) return fail(ctx, "rt_assemble_shards: bad arguments");
+    if (ctx->host_only) return fail(ctx, (std::string(who) + ": host-only context (created with device = -1)").c_str());
+    if (!gathered || n_shards < 1 || stride_bytes % 256) return fail(ctx, (std::string(who) + ": bad arguments").c_str());
     HIPCK(hipSetDevice(ctx->cfg.device));
     uint32_t stride = (uint32_t)(stride_bytes / 4);
     uint64_t total = (uint64_t)stride * (uint64_t)n_shards;
     hipLaunchKernelGGL(k_assemble, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)gathered,
-                       stride, n_shards, ctx->g, ctx->d_rgba);
+                       stride, n_shards, ctx->g, target);
     HIPCK(hipGetLastError());
+    return 0;
+}
+
+int rt_assemble_shards(rt_ctx *ctx, const void *gathered, size_t stride_bytes, int32_t n_shards) {
+    if (assemble_into(ctx, "rt_assemble_shards", gathered, stride_bytes, n_shards, ctx ? ctx->d_rgba : nullptr)) return -1;
     ctx->traced = true;
+    return 0;
+}
+
+int rt_assemble_shards_canvas(rt_ctx *ctx, const void *gathered, size_t stride_bytes, int32_t n_shards) {
+    if (ctx && ctx->cfg.supersampling != 1) return fail(ctx, "rt_assemble_shards_canvas: needs supersampling 1 (canvas and render target have one geometry then)");
+    return assemble_into(ctx, "rt_assemble_shards_canvas", gathered, stride_bytes, n_shards, ctx ? ctx->d_canvas : nullptr);
+}
+
+int rt_present_shard(rt_ctx *ctx) {
+    if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_present_shard: host-only context (created with device = -1)");
+    if (!ctx->traced) return fail(ctx, "rt_present_shard: nothing traced yet");
+    if (ctx->cfg.supersampling != 1) return fail(ctx, "rt_present_shard: needs supersampling 1 (with more the shader reads across tiles: present the assembled frame on the root)");
+    HIPCK(hipSetDevice(ctx->cfg.device));
+    const rt_config &c = ctx->cfg;
+    if (ctx->n0) {
+        hipLaunchKernelGGL(k_present_compact, dim3((ctx->n0 + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_compact, ctx->n0, c.tr_method,
+                           c.L_max, c.L_dmax, c.A, ctx->d_tone, ctx->d_compact_canvas);
+        HIPCK(hipGetLastError());
+    }
+    return 0;
+}
+
+int rt_device_shard_canvas(rt_ctx *ctx, void **dptr, size_t *bytes) {
+    if (!ctx) return -1;
+    if (ctx->host_only) return fail(ctx, "rt_device_shard_canvas: host-only context (created with device = -1)");
+    if (dptr) *dptr = ctx->d_compact_canvas;
+    if (bytes) *bytes = (size_t)ctx->n0 * 4;
     return 0;
 }
 

@@ -1011,6 +1011,25 @@ __global__ void k_set_tone(double Lbar, double sf, float *tone, double *tone_d) 
 // Present pass, js/8-kd_tree.js:85-143: S x S NEAREST taps (offsets divide by 800*S / 600*S, the WIDTH and
 // HEIGHT the reference script holds when it builds the shader string, js/8-kd_tree.js:55,110-111), scale by
 // L_MAX, Ward (x sf) or Reinhard, divide by L_DMAX, quantise.
+// tone operator and quantisation of the present shader for one output pixel (js/8-kd_tree.js:118-141)
+__device__ __forceinline__ uint32_t tone_pixel(const float (&acc)[3], int S, int method, float L_max, float L_dmax, float Akey,
+                                               float Lbar, float sf) {
+    uint32_t out = 0xff000000u;
+    for (int k = 0; k < 3; k++) {
+        float c = acc[k] / (float)(S * S);
+        c *= L_max;
+        if (method == 0) {
+            c *= sf;
+        } else {
+            c = c * Akey / Lbar;
+            c = c * L_dmax / (1.0f + c);
+        }
+        c /= L_dmax;
+        out |= quant8(c) << (8 * k);
+    }
+    return out;
+}
+
 __global__ __launch_bounds__(256) void k_present(const uint32_t *rgba, int W, int H, int S, int method, float L_max,
                                                  float L_dmax, float Akey, const float *tone, uint32_t *canvas) {
     int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -1034,20 +1053,22 @@ __global__ __launch_bounds__(256) void k_present(const uint32_t *rgba, int W, in
             acc[1] += (float)((v >> 8) & 255u) / 255.0f;
             acc[2] += (float)((v >> 16) & 255u) / 255.0f;
         }
-    uint32_t out = 0xff000000u;
-    for (int k = 0; k < 3; k++) {
-        float c = acc[k] / (float)(S * S);
-        c *= L_max;
-        if (method == 0) {
-            c *= sf;
-        } else {
-            c = c * Akey / Lbar;
-            c = c * L_dmax / (1.0f + c);
-        }
-        c /= L_dmax;
-        out |= quant8(c) << (8 * k);
-    }
-    canvas[(size_t)y * W + x] = out;
+    canvas[(size_t)y * W + x] = tone_pixel(acc, S, method, L_max, L_dmax, Akey, Lbar, sf);
+}
+
+// The present pass on a shard's compact tiles, SUPERSAMPLING 1 only: there the shader reads exactly its own pixel of
+// the render target (floor(((x + 0.5) / W) * W) = x), so every rank can present its tiles before the gather and
+// the root only scatters finished canvas pixels.
+__global__ __launch_bounds__(256) void k_present_compact(const uint32_t *compact, uint32_t n, int method, float L_max, float L_dmax,
+                                                         float Akey, const float *tone, uint32_t *out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = compact[i];
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    acc[0] += (float)(v & 255u) / 255.0f;
+    acc[1] += (float)((v >> 8) & 255u) / 255.0f;
+    acc[2] += (float)((v >> 16) & 255u) / 255.0f;
+    out[i] = tone_pixel(acc, 1, method, L_max, L_dmax, Akey, tone[0], tone[1]);
 }
 
 // scatter gathered shard-compact buffers (each `stride` pixels long) into the full-frame RGBA8 target

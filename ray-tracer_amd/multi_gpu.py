@@ -5,7 +5,8 @@ fragment shader reads only uniforms and textures, js/8-kd_tree.js:1060-1069). Tw
   1. the log-average luminance is a whole-image statistic (js/8-kd_tree.js:2559-2568): each rank reduces
      its own tiles to (sum log(EPS+L), pixel count) and the two numbers are all-reduced (SUM);
   2. the finished RGBA8 tiles are gathered to rank 0, which scatters them into the full frame and runs the
-     present pass.
+     present pass - or, with SUPERSAMPLING 1 (where the present shader reads only its own pixel), every rank runs
+     the present pass over its own tiles first and rank 0 only scatters finished canvas tiles (present="shards").
 The same FrameJob drives a CPU stand-in over gloo in the tests.
 """
 import ctypes as C
@@ -125,6 +126,10 @@ class HipShard:
         sc = max(rt.cfg.shard_count, 1)
         self.stride = ((g_tiles + sc - 1) // sc) * 256
         self.staging = torch.zeros(self.stride, dtype=torch.uint8, device=device)
+        # the same tiles after the present pass (rt_present_shard), supersampling 1 only
+        self.can_present_shard = rt.cfg.supersampling == 1
+        rt._ck(rt.L.rt_device_shard_canvas(rt.ctx, C.byref(p), C.byref(n)), "rt_device_shard_canvas")
+        self.compact_canvas = torch.as_tensor(_DevView(p.value, n.value), device=device) if n.value else None
 
     def trace(self):
         self.rt.trace()
@@ -142,6 +147,19 @@ class HipShard:
         self.rt._ck(self.rt.L.rt_assemble_shards(self.rt.ctx, C.c_void_p(gathered.data_ptr()), C.c_size_t(stride), world),
                     "rt_assemble_shards")
 
+    def present_shard(self):
+        self.rt.presentShard()
+
+    def shard_canvas_bytes(self):
+        if self.compact_canvas is not None:
+            self.staging[:self.compact_canvas.numel()].copy_(self.compact_canvas)
+        return self.staging, self.stride
+
+    def assemble_canvas(self, gathered, stride, world):
+        self.torch.cuda.synchronize()
+        self.rt._ck(self.rt.L.rt_assemble_shards_canvas(self.rt.ctx, C.c_void_p(gathered.data_ptr()), C.c_size_t(stride), world),
+                    "rt_assemble_shards_canvas")
+
     def tone_finish(self, s, n):
         return self.rt.toneFinish(s, n)
 
@@ -152,15 +170,30 @@ class HipShard:
 class FrameJob:
     """One frame across all ranks: trace -> luminance all-reduce -> tile gather -> assemble -> present."""
 
-    def __init__(self, rt_or_shard, comm):
+    def __init__(self, rt_or_shard, comm, present="auto"):
+        """present: "root" = rank 0 assembles the render target and presents it; "shards" = every rank presents its own
+        tiles and rank 0 assembles the canvas (rank 0 then holds the finished canvas, but only its own tiles of the
+        render target); "auto" = "shards" where the shard can (supersampling 1), else "root"."""
         self.comm = comm
         self.shard = rt_or_shard if hasattr(rt_or_shard, "tone_partial") else HipShard(rt_or_shard, comm.device)
+        able = bool(getattr(self.shard, "can_present_shard", False))
+        assert present in ("auto", "root", "shards") and (present != "shards" or able)
+        self.by_shards = able if present == "auto" else present == "shards"
         self.Lbar = self.sf = None
 
     def step(self):
         sh, comm = self.shard, self.comm
         sh.trace()
         s, n = sh.tone_partial()
+        if comm.world > 1 and self.by_shards:
+            s, n = comm.allreduce_tone(s, n)
+            self.Lbar, self.sf = sh.tone_finish(s, n)     # every rank: the tone values of the whole image
+            sh.present_shard()
+            buf, stride = sh.shard_canvas_bytes()
+            gathered = comm.gather_bytes(buf, stride)
+            if comm.rank == 0:
+                sh.assemble_canvas(gathered, stride, comm.world)
+            return self.Lbar, self.sf
         if comm.world > 1:
             s, n = comm.allreduce_tone(s, n)
             buf, stride = sh.shard_bytes()
@@ -182,16 +215,25 @@ class PipelinedFrameJob:
     step later - for the trace's buffer check (rt_trace_end). While the exchange of frame i runs, the kernels of frame
     i+1 (another context, another stream) fill the GPU. Needs device-side collectives: backend "nccl", or one rank."""
 
-    def __init__(self, rts, comm):
+    def __init__(self, rts, comm, present="auto", rehearse=None):
+        """rehearse = (role, n_shards), single rank only: the contexts are shards of an n_shards-way split and every
+        frame does the device work of one rank of such a job without the collectives - "worker": trace, sums, present
+        of the own tiles; "root": also the scatter of n_shards gathered canvas buffers (whatever they hold)."""
         import torch
         assert comm.dist is None or comm.backend == "nccl", "the pipelined job needs RCCL (or a single rank)"
         self.torch, self.comm = torch, comm
+        able = all(rt.cfg.supersampling == 1 for rt in rts)
+        assert present in ("auto", "root", "shards") and (present != "shards" or able)
+        self.by_shards = (able if present == "auto" else present == "shards") and comm.dist is not None   # see FrameJob
+        self.rehearse = rehearse if (rehearse and comm.dist is None and able) else None
         self.slots = []
         for rt in rts:
             sh = HipShard(rt, comm.device)
             st = torch.cuda.ExternalStream(rt.stream(), device=comm.device)
             gathered = (torch.empty(comm.world * sh.stride, dtype=torch.uint8, device=comm.device)
                         if comm.rank == 0 and comm.dist is not None else None)
+            if self.rehearse and self.rehearse[0] == "root":
+                gathered = torch.zeros(self.rehearse[1] * sh.stride, dtype=torch.uint8, device=comm.device)
             self.slots.append({"rt": rt, "shard": sh, "stream": st, "gathered": gathered, "busy": False, "pair": None})
         self.i = 0
         self.redone = 0
@@ -204,6 +246,25 @@ class PipelinedFrameJob:
         dptr = rt.tonePartialDevice()
         if slot["pair"] is None:
             slot["pair"] = torch.as_tensor(_DevView64(dptr, 2), device=comm.device)
+        if self.rehearse:
+            rt.toneFinishDevice(dptr)
+            rt.presentShard()
+            buf, stride = sh.shard_canvas_bytes()
+            if self.rehearse[0] == "root":
+                rt._ck(rt.L.rt_assemble_shards_canvas(rt.ctx, C.c_void_p(slot["gathered"].data_ptr()), C.c_size_t(stride), self.rehearse[1]),
+                       "rt_assemble_shards_canvas")
+            return
+        if self.by_shards:
+            comm.dist.all_reduce(slot["pair"])
+            rt.toneFinishDevice(dptr)
+            rt.presentShard()
+            buf, stride = sh.shard_canvas_bytes()
+            parts = list(slot["gathered"].split(stride)) if comm.rank == 0 else None
+            comm.dist.gather(buf, gather_list=parts, dst=0)
+            if comm.rank == 0:
+                rt._ck(rt.L.rt_assemble_shards_canvas(rt.ctx, C.c_void_p(slot["gathered"].data_ptr()), C.c_size_t(stride), comm.world),
+                       "rt_assemble_shards_canvas")
+            return
         if comm.dist is not None:
             comm.dist.all_reduce(slot["pair"])
             buf, stride = sh.shard_bytes()

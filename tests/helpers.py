@@ -72,3 +72,14 @@ def make_flat(model_name=None, width=640, height=480, depth=1, ss=1, time=0.0, m
         scene.animate_light(sc, time)
     cfg = abi.default_config(width, height, depth=depth, supersampling=ss, **cfg_kw)
     return abi.FlatScene(sc, cfg, scene.camera_rays(width, height))
+
+
+def device_canvas(rt):
+    """The presented canvas as it sits in device memory (no present pass is run), [H, W, 4] uint8."""
+    import ctypes as C
+    import torch
+    from ray_tracer_amd import multi_gpu
+    p, n = C.c_void_p(), C.c_size_t()
+    rt._ck(rt.L.rt_device_canvas(rt.ctx, C.byref(p), C.byref(n)), "rt_device_canvas")
+    torch.cuda.synchronize()
+    return torch.as_tensor(multi_gpu._DevView(p.value, n.value), device="cuda:%d" % rt.cfg.device).cpu().numpy().reshape(rt.cfg.height, rt.cfg.width, 4)

@@ -8,7 +8,7 @@ reduction sums in a different order."""
 import numpy as np
 import pytest
 
-from helpers import make_flat, manifest, sha
+from helpers import device_canvas, make_flat, manifest, sha
 from oracle import oracle
 from ray_tracer_amd import abi
 
@@ -321,19 +321,30 @@ def test_pipelined_job_with_device_collectives_one_rank():
         rts.append(rt)
     comm = multi_gpu.Comm(0, 1, 0, backend="nccl", device="cuda:0", single_rank_group=True)
     try:
-        job = multi_gpu.PipelinedFrameJob(rts, comm)
-        for _ in range(4):
-            job.step()
-        job.flush()
-        torch.cuda.synchronize()
         ref = abi.RayTracerHIP(flat.cfg)
         ref.setScene(flat)
         ref.trace()
         wl, ws = ref.tone()
-        for rt in rts:
-            assert np.array_equal(rt.readRGBA8(), ref.readRGBA8())
-            gl, gs = rt.toneGet()
-            assert abs(gl - wl) <= 1e-12 * wl and np.float32(gs) == np.float32(ws)
+        want_canvas = ref.present().reshape(flat.cfg.height, flat.cfg.width, 4)
+        # "root": the root assembles the render target and presents it; "shards": every rank presents its own tiles
+        # (rt_present_shard) and the root assembles the canvas
+        for mode in ("root", "shards"):
+            job = multi_gpu.PipelinedFrameJob(rts, comm, present=mode)
+            assert job.by_shards == (mode == "shards")
+            for rt in rts:   # no canvas left over from the other mode
+                p, n = abi.C.c_void_p(), abi.C.c_size_t()
+                rt._ck(rt.L.rt_device_canvas(rt.ctx, abi.C.byref(p), abi.C.byref(n)), "rt_device_canvas")
+                torch.as_tensor(multi_gpu._DevView(p.value, n.value), device="cuda:0").zero_()
+            torch.cuda.synchronize()
+            for _ in range(4):
+                job.step()
+            job.flush()
+            torch.cuda.synchronize()
+            for rt in rts:
+                assert np.array_equal(rt.readRGBA8(), ref.readRGBA8())
+                gl, gs = rt.toneGet()
+                assert abs(gl - wl) <= 1e-12 * wl and np.float32(gs) == np.float32(ws)
+                assert np.array_equal(device_canvas(rt), want_canvas), mode
     finally:
         comm.close()
 

@@ -146,16 +146,28 @@ def hip_worker(rank, world, port, out):
     rt = abi.RayTracerHIP(flat.cfg)
     rt.setScene(flat)
     comm = multi_gpu.Comm(rank, world, 0, backend="gloo", device="cuda:0")
+    def canvas_hash():
+        p, n = abi.C.c_void_p(), abi.C.c_size_t()
+        rt._ck(rt.L.rt_device_canvas(rt.ctx, abi.C.byref(p), abi.C.byref(n)), "rt_device_canvas")
+        torch.cuda.synchronize()
+        canvas = torch.as_tensor(multi_gpu._DevView(p.value, n.value), device="cuda:0").cpu().numpy()
+        return hashlib.sha256(canvas.tobytes()).hexdigest()
+
+    # every rank presents its own tiles, the root assembles the canvas (what "auto" picks at supersampling 1) ...
     job = multi_gpu.FrameJob(rt, comm)
+    assert job.by_shards
     for _ in range(2):
         Lbar, sf = job.step()
     res = {"rank": rank, "Lbar": Lbar, "sf": sf, "rays": int(rt.stats().rays_total)}
     if rank == 0:
+        res["canvas_by_shards"] = canvas_hash()
+    # ... and the root assembling the render target and presenting it
+    job = multi_gpu.FrameJob(rt, comm, present="root")
+    Lbar2, sf2 = job.step()
+    assert (Lbar2, sf2) == (Lbar, sf)
+    if rank == 0:
         res["rgba"] = hashlib.sha256(np.ascontiguousarray(rt.readRGBA8()).tobytes()).hexdigest()
-        p, n = abi.C.c_void_p(), abi.C.c_size_t()
-        rt._ck(rt.L.rt_device_canvas(rt.ctx, abi.C.byref(p), abi.C.byref(n)), "rt_device_canvas")
-        canvas = torch.as_tensor(multi_gpu._DevView(p.value, n.value), device="cuda:0").cpu().numpy()
-        res["canvas"] = hashlib.sha256(canvas.tobytes()).hexdigest()
+        res["canvas"] = canvas_hash()
     out.put(res)
     comm.close()
     rt.close()
@@ -184,6 +196,7 @@ def test_two_hip_shards_equal_one_context():
     canvas = rt.present()
     assert results[0]["rgba"] == hashlib.sha256(np.ascontiguousarray(rt.readRGBA8()).tobytes()).hexdigest()
     assert results[0]["canvas"] == hashlib.sha256(np.ascontiguousarray(canvas).tobytes()).hexdigest()
+    assert results[0]["canvas_by_shards"] == results[0]["canvas"]
     assert results[0]["rays"] + results[1]["rays"] == rt.stats().rays_total
     for r in results.values():
         assert abs(r["Lbar"] - Lbar) <= 1e-10 * Lbar and np.float32(r["sf"]) == np.float32(sf)
