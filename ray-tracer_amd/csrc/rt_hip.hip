@@ -516,7 +516,9 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     g.W = cfg->width * cfg->supersampling;
     g.H = cfg->height * cfg->supersampling;
     g.tiles_x = (g.W + 7) / 8;
-    g.n_tiles = g.tiles_x * ((g.H + 7) / 8);
+    g.tiles_y = (g.H + 7) / 8;
+    g.blocks_x = (g.tiles_x + TILE_BLOCK - 1) / TILE_BLOCK;
+    g.n_tiles = g.blocks_x * ((g.tiles_y + TILE_BLOCK - 1) / TILE_BLOCK) * TILE_BLOCK * TILE_BLOCK;   // whole blocks (tile_coords)
     g.shard_index = cfg->shard_index;
     g.shard_count = sc;
     g.compact_mul = 1;
@@ -908,8 +910,8 @@ static int collect_stats(rt_ctx *ctx) {
         uint64_t px = 0;
         const FrameGeom &g = ctx->g;
         for (int t = g.shard_index; t < g.n_tiles; t += g.shard_count) {
-            int tx = t % g.tiles_x, ty = t / g.tiles_x;
-            px += (uint64_t)std::min(8, g.W - tx * 8) * (uint64_t)std::min(8, g.H - ty * 8);
+            int tx, ty;
+            if (tile_coords(g, (uint32_t)t, tx, ty)) px += (uint64_t)std::min(8, g.W - tx * 8) * (uint64_t)std::min(8, g.H - ty * 8);
         }
         st.pixels = px;
         st.rays_per_level[0] = px;
@@ -1086,7 +1088,7 @@ int rt_pick(rt_ctx *ctx, int32_t x, int32_t y, int32_t *id) {
     if (!ctx->traced) return fail(ctx, "rt_pick: nothing traced yet");
     if (ctx->in_flight) return fail(ctx, "rt_pick: a frame is in flight, call rt_trace_end first");
     if (x < 0 || y < 0 || x >= ctx->g.W || y >= ctx->g.H) return fail(ctx, "rt_pick: pixel outside the render target");
-    if (((y / 8) * ctx->g.tiles_x + x / 8) % ctx->g.shard_count != ctx->g.shard_index)
+    if ((int)(tile_index(ctx->g, x / 8, y / 8) % (uint32_t)ctx->g.shard_count) != ctx->g.shard_index)
         return fail(ctx, "rt_pick: the pixel belongs to another shard (primary hit ids are not gathered)");
     HIPCK(hipSetDevice(ctx->cfg.device));
     HIPCK(hipMemcpy(id, ctx->d_hit + (size_t)y * ctx->g.W + x, sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -54,7 +54,8 @@ constexpr int SHADOWQ_ARRAYS = 9;
 constexpr int MAX_LIGHTS = 32;
 
 struct FrameGeom {
-    int32_t W, H, tiles_x, n_tiles;
+    int32_t W, H, tiles_x, n_tiles;      // n_tiles counts the padded enumeration below
+    int32_t tiles_y, blocks_x;
     int32_t shard_index, shard_count;   // level-0 entry tid belongs to tile shard_index + (tid >> 6) * shard_count
     int32_t compact_mul, compact_add;   // and to tile (tid >> 6) * compact_mul + compact_add of the shard's compact buffer
 };
@@ -88,12 +89,39 @@ struct LevelArgs {
     int32_t level, last_level;
 };
 
+// Order of the 8x8-pixel tiles. Level 0 lists its rays tile by tile, every deeper level and every queue keeps that
+// order, and the walk hands out neighbouring chunks of a queue to one XCD at a time: neighbours in this order should be
+// neighbours in the image in BOTH directions, so that they cross the same nodes and triangles. The tiles are therefore
+// numbered in blocks of 16 x 16 tiles (128 x 128 pixels), Z-order (Morton) inside a block, the blocks row by row;
+// the numbering runs over whole blocks, tiles beyond the image edge exist in it and hold no pixels.
+__host__ __device__ __forceinline__ uint32_t even_bits(uint32_t w) {   // bits 0, 2, 4, 6 of w -> a 4-bit number
+    w &= 0x55u;
+    w = (w | (w >> 1)) & 0x33u;
+    return (w | (w >> 2)) & 0x0fu;
+}
+__host__ __device__ __forceinline__ uint32_t spread_bits(uint32_t v) {   // a 4-bit number -> bits 0, 2, 4, 6
+    v = (v | (v << 2)) & 0x33u;
+    return (v | (v << 1)) & 0x55u;
+}
+constexpr int TILE_BLOCK = 16;   // tiles per block side
+__host__ __device__ __forceinline__ bool tile_coords(const FrameGeom &g, uint32_t tile, int &tx, int &ty) {
+    const uint32_t block = tile >> 8, w = tile & 255u;
+    tx = (int)((block % (uint32_t)g.blocks_x) * TILE_BLOCK + even_bits(w));
+    ty = (int)((block / (uint32_t)g.blocks_x) * TILE_BLOCK + even_bits(w >> 1));
+    return tile < (uint32_t)g.n_tiles && tx < g.tiles_x && ty < g.tiles_y;
+}
+__host__ __device__ __forceinline__ uint32_t tile_index(const FrameGeom &g, int tx, int ty) {
+    const uint32_t block = (uint32_t)(ty / TILE_BLOCK) * (uint32_t)g.blocks_x + (uint32_t)(tx / TILE_BLOCK);
+    return (block << 8) | spread_bits((uint32_t)tx & 15u) | (spread_bits((uint32_t)ty & 15u) << 1);
+}
+
 __device__ __forceinline__ bool pixel_of(const FrameGeom &g, uint32_t tid, int &x, int &y) {
-    uint32_t tile = (uint32_t)g.shard_index + (tid >> 6) * (uint32_t)g.shard_count;
-    if (tile >= (uint32_t)g.n_tiles) return false;
-    uint32_t lane = tid & 63u;
-    x = (int)(tile % (uint32_t)g.tiles_x) * 8 + (int)(lane & 7u);
-    y = (int)(tile / (uint32_t)g.tiles_x) * 8 + (int)(lane >> 3);
+    const uint32_t tile = (uint32_t)g.shard_index + (tid >> 6) * (uint32_t)g.shard_count;
+    int tx, ty;
+    if (!tile_coords(g, tile, tx, ty)) return false;
+    const uint32_t lane = tid & 63u;
+    x = tx * 8 + (int)(lane & 7u);
+    y = ty * 8 + (int)(lane >> 3);
     return x < g.W && y < g.H;
 }
 

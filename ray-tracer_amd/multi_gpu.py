@@ -122,7 +122,8 @@ class HipShard:
         rt._ck(rt.L.rt_device_shard_rgba8(rt.ctx, C.byref(p), C.byref(n)), "rt_device_shard_rgba8")
         # a shard without tiles (more ranks than tiles) has nothing to copy: no view over zero bytes
         self.compact = torch.as_tensor(_DevView(p.value, n.value), device=device) if n.value else None
-        g_tiles = ((rt.W + 7) // 8) * ((rt.H + 7) // 8)
+        # the library numbers the 8x8 tiles over whole blocks of 16 x 16 tiles (rt_kernels.h: tile_coords)
+        g_tiles = (((rt.W + 7) // 8 + 15) // 16) * (((rt.H + 7) // 8 + 15) // 16) * 256
         sc = max(rt.cfg.shard_count, 1)
         self.stride = ((g_tiles + sc - 1) // sc) * 256
         self.staging = torch.zeros(self.stride, dtype=torch.uint8, device=device)
