@@ -19,7 +19,8 @@ struct GpuKdTree {
     KdNodeDev *nodes = nullptr;     // treelet layout (see relayout_treelets in kd_build.cpp), leaves in device form
     uint32_t n_node_slots = 0;
     TriDev *tris = nullptr;         // face order
-    TriDev *ltris = nullptr;        // leaf order
+    TriGeo *lgeo = nullptr;         // leaf order: what a triangle test reads
+    TriTag *ltag = nullptr;         // leaf order: what the winner of a ray needs
     uint32_t n_slots = 0;
     uint32_t *path_slot = nullptr;  // 2^PATH_BITS entries
     uint2 *pairs = nullptr;         // (heap index, reference metadata) of every node, unordered

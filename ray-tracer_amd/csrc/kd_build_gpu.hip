@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_kd_make_tris(const double *verts, const
     for (int k = 0; k < 3; k++) { t.v0[k] = v[0][k]; t.e1[k] = v[1][k] - v[0][k]; t.e2[k] = v[2][k] - v[0][k]; }
     t.mat = face_mat[f];
     t.face = (int32_t)f;
-    t.code = 0;
+    t.pad = 0;
     tris[f] = t;
 }
 
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_kd_leaf_mark(const uint32_t *leaf_heap,
 __global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap, const uint32_t *leaf_count, const uint32_t *leaf_pos,
                                                       const uint32_t *leaf_faces, const uint32_t *n_leaves, uint32_t bound,
                                                       const unsigned long long *code_scan, const TriDev *tris, uint32_t n_tris, KdNodeDev *nodes,
-                                                      uint32_t node_cap, TriDev *ltris, uint32_t cap_slots, uint32_t *path_slot,
+                                                      uint32_t node_cap, TriGeo *lgeo, TriTag *ltag, uint32_t cap_slots, uint32_t *path_slot,
                                                       int32_t *leaves, uint2 *pairs, uint32_t cap_pairs, uint32_t *counters) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= min(*n_leaves, bound)) return;
@@ -308,9 +308,11 @@ __global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap,
         const uint32_t f = leaf_faces[4 * (size_t)i + k];
         leaves[4 * (size_t)number + k] = k < cnt ? (int32_t)f : -1;
         if (k < cnt && first + k < cap_slots && f < n_tris) {
-            TriDev t = tris[f];
-            t.code = code;
-            ltris[first + k] = t;
+            const TriDev t = tris[f];
+            TriGeo g;
+            for (int c = 0; c < 3; c++) { g.v0[c] = t.v0[c]; g.e1[c] = t.e1[c]; g.e2[c] = t.e2[c]; }
+            lgeo[first + k] = g;
+            ltag[first + k] = TriTag{t.mat, t.face, code, 0u};
         }
     }
     const uint32_t pi = atomicAdd(&counters[C_PAIRS], 1u);
@@ -359,7 +361,7 @@ GpuKdBuilder::~GpuKdBuilder() { release(); }
 void GpuKdBuilder::release() {
     void *ptrs[] = {d_verts, d_faces, d_face_mat, pool_face[0], pool_face[1], pool_owner[0], pool_owner[1], flags, scanned,
                     child_flag, child_scan, child_count, child_start, owner_map, code_count, code_scan, leaf_heap, leaf_count,
-                    leaf_pos, leaf_faces, counters, lstate, scan_tmp, tree.nodes, tree.tris, tree.ltris, tree.path_slot, tree.pairs,
+                    leaf_pos, leaf_faces, counters, lstate, scan_tmp, tree.nodes, tree.tris, tree.lgeo, tree.ltag, tree.path_slot, tree.pairs,
                     tree.leaves};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -414,7 +416,7 @@ int GpuKdBuilder::reserve(int64_t n_verts, int64_t n_faces, std::string &err) {
     if (want_leaves > cap_leaves) {
         if (grow(leaf_heap, want_leaves, err) || grow(leaf_count, want_leaves, err) || grow(leaf_pos, want_leaves, err) ||
             grow(leaf_faces, 4 * (size_t)want_leaves, err) || grow(tree.leaves, 4 * (size_t)want_leaves, err) ||
-            grow(tree.ltris, 4 * (size_t)want_leaves, err))
+            grow(tree.lgeo, 4 * (size_t)want_leaves, err) || grow(tree.ltag, 4 * (size_t)want_leaves, err))
             return -1;
         cap_leaves = want_leaves;
         cap_leaf_table = want_leaves;
@@ -590,7 +592,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     size_t tmp = scan_tmp_bytes;
     KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, code_count, code_scan, (int)(CODES + 1), s));
     hipLaunchKernelGGL(k_kd_leaf_emit, blocks_for(grid_leaves), dim3(256), 0, s, leaf_heap, leaf_count, leaf_pos, leaf_faces,
-                       counters + C_LEAVES, grid_leaves, code_scan, tree.tris, nf, tree.nodes, cap_node_slots, tree.ltris, cap_slots,
+                       counters + C_LEAVES, grid_leaves, code_scan, tree.tris, nf, tree.nodes, cap_node_slots, tree.lgeo, tree.ltag, cap_slots,
                        tree.path_slot, tree.leaves, tree.pairs, cap_pairs, counters);
     KCK(hipGetLastError());
     KCK(hipMemcpyAsync(h_total, code_scan + CODES, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -35,14 +35,25 @@ struct LightDev {
 
 // Triangle as the traversal wants it: vertex 0 and the two edges the reference's Moller-Trumbore
 // forms first (e1 = v1 - v0, e2 = v2 - v0 in float32, js/8-kd_tree.js:505-506), then material and face index.
-// Two arrays hold these records: `tris` indexed by face, and `ltris` in leaf order - the (at most four) faces
-// of leaf 0, then those of leaf 1, ... - so that a leaf visit can name its triangles as a slot range without
-// reading a leaf record.
+// `tris` holds these records indexed by face.
 struct TriDev {
     float v0[3], e1[3], e2[3];
     int32_t mat;
     int32_t face;
-    uint32_t code;                // `ltris` only: path code of the leaf that lists this slot (see path_code)
+    uint32_t pad;
+};
+// The walk reads the triangles in leaf order - the (at most four) faces of leaf 0, then those of leaf 1, ... - so
+// that a leaf visit can name its triangles as a slot range without reading a leaf record. That table is by far the
+// largest thing the walk touches (a face is listed by every leaf it overlaps), so it holds only what a test needs:
+// 36 bytes a slot in `lgeo`. What only the winner of a ray needs sits beside it in `ltag`.
+struct TriGeo {
+    float v0[3], e1[3], e2[3];
+};
+struct TriTag {
+    int32_t mat;
+    int32_t face;
+    uint32_t code;                // path code of the leaf that lists this slot (see path_code)
+    uint32_t pad;
 };
 
 // Position of a node in the tree as a bit string: one bit per level below the root, 0 = lower child, 1 = upper
@@ -67,7 +78,7 @@ inline uint32_t path_code(uint32_t heap) {
 }
 
 // Device copy of a k-d node (see kd_build.h for internal nodes). Leaf info differs from the host form:
-// [31:30] = 3, [25:24] = number of faces - 1 (a leaf with faces has 1..4), [23:0] = first slot in `ltris`.
+// [31:30] = 3, [25:24] = number of faces - 1 (a leaf with faces has 1..4), [23:0] = first slot in `lgeo` / `ltag`.
 // The low 26 bits are, as they stand, the record a walking lane puts into its wave's ring of pending triangle tests.
 constexpr uint32_t LEAF_COUNT_SHIFT = 24;
 constexpr uint32_t LEAF_SLOT_MASK = (1u << LEAF_COUNT_SHIFT) - 1u;
@@ -88,8 +99,9 @@ struct SceneDev {
     const LightDev *lights;
     const TriDev *tris;
     const KdNodeDev *nodes;
-    const TriDev *ltris;
-    const uint32_t *path_slot;    // path code of a non-empty leaf -> its first slot in `ltris` (2^PATH_BITS entries)
+    const TriGeo *lgeo;
+    const TriTag *ltag;
+    const uint32_t *path_slot;    // path code of a non-empty leaf -> its first slot in `lgeo` (2^PATH_BITS entries)
 };
 
 struct V3 {
@@ -307,6 +319,9 @@ __device__ __forceinline__ bool hit_tri_regs(V3 v0, V3 e1, V3 e2, float tri_eps,
     return true;
 }
 __device__ __forceinline__ bool hit_tri(const TriDev &T, float tri_eps, V3 ro, V3 rd, float &t) {
+    return hit_tri_regs(ld3(T.v0), ld3(T.e1), ld3(T.e2), tri_eps, ro, rd, t);
+}
+__device__ __forceinline__ bool hit_tri(const TriGeo &T, float tri_eps, V3 ro, V3 rd, float &t) {
     return hit_tri_regs(ld3(T.v0), ld3(T.e1), ld3(T.e2), tri_eps, ro, rd, t);
 }
 

@@ -24,16 +24,17 @@ namespace {
 
 thread_local std::string g_create_error;
 
-// Device form of a k-d tree (nodes, leaf-ordered triangles, path table), shared by every context of the process that
+// Device form of a k-d tree (nodes, the two leaf-ordered triangle tables, path table), shared by every context of the process that
 // uploads the same tree to the same GPU: a pipeline keeps several contexts with the same scene in flight, and their
 // walks run side by side - one copy keeps the L2 caches for one tree instead of one per context. Immutable once
 // registered; the last context to let go frees it.
 struct SharedTree {
     int device = 0;
     unsigned long long hash = 0;
-    size_t n_nodes = 0, n_ltris = 0;
+    size_t n_nodes = 0, n_slots = 0;
     KdNodeDev *nodes = nullptr;
-    TriDev *ltris = nullptr;
+    TriGeo *lgeo = nullptr;
+    TriTag *ltag = nullptr;
     uint32_t *path_slot = nullptr;
     int refs = 0;
 };
@@ -122,10 +123,11 @@ struct rt_ctx {
     LightDev *d_lights = nullptr;
     TriDev *d_tris = nullptr;
     KdNodeDev *d_nodes = nullptr;
-    TriDev *d_ltris = nullptr;
+    TriGeo *d_lgeo = nullptr;                    // leaf-ordered triangles: geometry for the tests ...
+    TriTag *d_ltag = nullptr;                    // ... and material, face, leaf code for the winners
     uint2 *d_path_first = nullptr;               // staging of (path code, first slot) pairs
     uint32_t *d_path_slot = nullptr;             // 2^PATH_BITS entries, SceneDev::path_slot
-    SharedTree *shared = nullptr;                // d_nodes, d_ltris and d_path_slot belong to this shared copy, not to the context
+    SharedTree *shared = nullptr;                // d_nodes, d_lgeo, d_ltag and d_path_slot belong to this shared copy, not to the context
     bool tree_dirty = true;
     size_t cap_prims = 0, cap_mats = 0, cap_lights = 0, cap_tris = 0, cap_path_first = 0;
     // frame
@@ -233,13 +235,14 @@ void detach_shared_tree(rt_ctx *ctx) {
     SharedTree *t = ctx->shared;
     if (--t->refs == 0) {
         (void)hipFree(t->nodes);
-        (void)hipFree(t->ltris);
+        (void)hipFree(t->lgeo);
+        (void)hipFree(t->ltag);
         (void)hipFree(t->path_slot);
         g_shared.erase(std::remove(g_shared.begin(), g_shared.end(), t), g_shared.end());
         delete t;
     }
     ctx->shared = nullptr;
-    ctx->d_nodes = nullptr; ctx->d_ltris = nullptr; ctx->d_path_slot = nullptr;
+    ctx->d_nodes = nullptr; ctx->d_lgeo = nullptr; ctx->d_ltag = nullptr; ctx->d_path_slot = nullptr;
 }
 
 int ensure_queues(rt_ctx *ctx, Part &P, int level, uint32_t n_rays, uint32_t n_lights) {
@@ -333,7 +336,7 @@ int upload_scene(rt_ctx *ctx) {
             for (int k = 0; k < 3; k++) { t.v0[k] = v[0][k]; t.e1[k] = v[1][k] - v[0][k]; t.e2[k] = v[2][k] - v[0][k]; }
             t.mat = find_mat((int)ctx->face_mat[2 * f], (int)ctx->face_mat[2 * f + 1]);
             t.face = (int32_t)f;
-            t.code = 0;
+            t.pad = 0;
         }
         if (ensure(ctx, ctx->d_tris, ctx->cap_tris, nf)) return -1;
         if (nf) HIPCK(hipMemcpyAsync(ctx->d_tris, tris.data(), nf * sizeof(TriDev), hipMemcpyHostToDevice, ctx->stream));
@@ -353,11 +356,17 @@ int upload_scene(rt_ctx *ctx) {
             first[i + 1] = first[i] + c;
         }
         if (first.back() > (1u << LEAF_COUNT_SHIFT)) return fail(ctx, "k-d tree has too many leaf slots for the device layout (2^24)");
-        std::vector<TriDev> ltris(first.back());
+        std::vector<TriGeo> lgeo(first.back());
+        std::vector<TriTag> ltag(first.back());
         for (size_t i = 0; i < kd.leaves.size(); i++) {
             uint32_t s0 = first[i];
             for (int k = 0; k < 4; k++)
-                if (kd.leaves[i].face[k] > -1) ltris[s0++] = ctx->tris_host[(size_t)kd.leaves[i].face[k]];
+                if (kd.leaves[i].face[k] > -1) {
+                    const TriDev &t = ctx->tris_host[(size_t)kd.leaves[i].face[k]];
+                    memcpy(lgeo[s0].v0, t.v0, sizeof(TriGeo));   // v0, e1, e2 lie in this order in both records
+                    ltag[s0] = TriTag{t.mat, t.face, 0u, 0u};
+                    s0++;
+                }
         }
         std::vector<KdNodeDev> nodes(kd.nodes);
         std::vector<uint2> path_first;   // (path code, first slot) of every non-empty leaf
@@ -368,17 +377,18 @@ int upload_scene(rt_ctx *ctx) {
                 const uint32_t li = n.info & 0x3fffffffu;
                 n.info = leaf_info(first[li + 1] - first[li], first[li]);
                 const uint32_t code = path_code(kd.heap_index[s]);
-                for (uint32_t k = first[li]; k < first[li + 1]; k++) ltris[k].code = code;
+                for (uint32_t k = first[li]; k < first[li + 1]; k++) ltag[k].code = code;
                 path_first.push_back(make_uint2(code, first[li]));
             }
         }
         detach_shared_tree(ctx);
         unsigned long long hash = fnv1a(nodes.data(), nodes.size() * sizeof(KdNodeDev));
-        hash = fnv1a(ltris.data(), ltris.size() * sizeof(TriDev), hash);
+        hash = fnv1a(lgeo.data(), lgeo.size() * sizeof(TriGeo), hash);
+        hash = fnv1a(ltag.data(), ltag.size() * sizeof(TriTag), hash);
         {   // another context of this process may hold this very tree on this GPU already
             std::lock_guard<std::mutex> lock(g_shared_mu);
             for (SharedTree *t : g_shared)
-                if (t->device == ctx->cfg.device && t->hash == hash && t->n_nodes == nodes.size() && t->n_ltris == ltris.size()) {
+                if (t->device == ctx->cfg.device && t->hash == hash && t->n_nodes == nodes.size() && t->n_slots == lgeo.size()) {
                     t->refs++;
                     ctx->shared = t;
                     break;
@@ -386,19 +396,22 @@ int upload_scene(rt_ctx *ctx) {
         }
         if (!ctx->shared) {
             SharedTree *t = new SharedTree();
-            t->device = ctx->cfg.device; t->hash = hash; t->n_nodes = nodes.size(); t->n_ltris = ltris.size(); t->refs = 1;
-            auto drop = [&]() { (void)hipFree(t->nodes); (void)hipFree(t->ltris); (void)hipFree(t->path_slot); delete t; };
+            t->device = ctx->cfg.device; t->hash = hash; t->n_nodes = nodes.size(); t->n_slots = lgeo.size(); t->refs = 1;
+            auto drop = [&]() { (void)hipFree(t->nodes); (void)hipFree(t->lgeo); (void)hipFree(t->ltag); (void)hipFree(t->path_slot); delete t; };
             hipError_t e;
             if ((e = hipMalloc((void **)&t->nodes, std::max<size_t>(nodes.size(), 1) * sizeof(KdNodeDev))) != hipSuccess ||
-                (e = hipMalloc((void **)&t->ltris, std::max<size_t>(ltris.size(), 1) * sizeof(TriDev))) != hipSuccess ||
+                (e = hipMalloc((void **)&t->lgeo, std::max<size_t>(lgeo.size(), 1) * sizeof(TriGeo))) != hipSuccess ||
+                (e = hipMalloc((void **)&t->ltag, std::max<size_t>(ltag.size(), 1) * sizeof(TriTag))) != hipSuccess ||
                 (e = hipMalloc((void **)&t->path_slot, sizeof(uint32_t) << PATH_BITS)) != hipSuccess) {
                 drop();
                 return fail(ctx, (std::string("hipMalloc (k-d tree): ") + hipGetErrorString(e)).c_str());
             }
             if (ensure(ctx, ctx->d_path_first, ctx->cap_path_first, path_first.size())) { drop(); return -1; }
             e = hipMemcpyAsync(t->nodes, nodes.data(), nodes.size() * sizeof(KdNodeDev), hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess && !ltris.empty())
-                e = hipMemcpyAsync(t->ltris, ltris.data(), ltris.size() * sizeof(TriDev), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess && !lgeo.empty())
+                e = hipMemcpyAsync(t->lgeo, lgeo.data(), lgeo.size() * sizeof(TriGeo), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess && !ltag.empty())
+                e = hipMemcpyAsync(t->ltag, ltag.data(), ltag.size() * sizeof(TriTag), hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess && !path_first.empty()) {
                 // only the entries of existing leaves are ever read, so the table is not cleared
                 e = hipMemcpyAsync(ctx->d_path_first, path_first.data(), path_first.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream);
@@ -414,7 +427,7 @@ int upload_scene(rt_ctx *ctx) {
             g_shared.push_back(t);
             ctx->shared = t;
         }
-        ctx->d_nodes = ctx->shared->nodes; ctx->d_ltris = ctx->shared->ltris; ctx->d_path_slot = ctx->shared->path_slot;
+        ctx->d_nodes = ctx->shared->nodes; ctx->d_lgeo = ctx->shared->lgeo; ctx->d_ltag = ctx->shared->ltag; ctx->d_path_slot = ctx->shared->path_slot;
         HIPCK(hipStreamSynchronize(ctx->stream));
         ctx->st.kd_upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         ctx->tree_dirty = false;
@@ -442,10 +455,10 @@ int upload_scene(rt_ctx *ctx) {
         }
     }
     h.prims = ctx->d_prims; h.mats = ctx->d_mats; h.lights = ctx->d_lights; h.tris = ctx->d_tris;
-    h.nodes = ctx->d_nodes; h.ltris = ctx->d_ltris; h.path_slot = ctx->d_path_slot;
+    h.nodes = ctx->d_nodes; h.lgeo = ctx->d_lgeo; h.ltag = ctx->d_ltag; h.path_slot = ctx->d_path_slot;
     if (ctx->kd_on_device) {
         const GpuKdTree &t = ctx->gpu_kd->tree;
-        h.tris = t.tris; h.nodes = t.nodes; h.ltris = t.ltris; h.path_slot = t.path_slot;
+        h.tris = t.tris; h.nodes = t.nodes; h.lgeo = t.lgeo; h.ltag = t.ltag; h.path_slot = t.path_slot;
     }
     HIPCK(hipMemcpyAsync(ctx->d_scene, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
     HIPCK(hipStreamSynchronize(ctx->stream));

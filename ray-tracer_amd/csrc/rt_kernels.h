@@ -306,7 +306,7 @@ constexpr int SHORT_STACK = RT_SHORT_STACK;          // power of two
 #define RT_MAIL_SLOTS 16
 #endif
 constexpr int MAIL_SLOTS = RT_MAIL_SLOTS;                      // stretches that change hands in one exchange of a wave
-// leaf records waiting for their triangle tests: lane << 26 | the low 26 bits of the leaf's info ((faces - 1) << 24 | first slot in S.ltris).
+// leaf records waiting for their triangle tests: lane << 26 | the low 26 bits of the leaf's info ((faces - 1) << 24 | first slot in S.lgeo).
 // The ring never holds more than 63 records when the lanes take their next actions.
 constexpr int TEST_RING = 256;
 #ifndef RT_WALK_ACTIONS
@@ -343,7 +343,7 @@ __device__ __forceinline__ bool test_round(const SceneDev &S, const WalkJob &J, 
     // Lanes beyond n (only when the ring is drained with fewer than 64 records) run the same code on slot 0 and
     // lane 0's ray and drop the result: with no branch around the arithmetic the triangle loads are issued first and
     // the permutes and the other lanes' work run under their latency
-    const TriDev *T = S.ltris + first;
+    const TriGeo *T = S.lgeo + first;
     const V3 v0 = ld3(T->v0), e1 = ld3(T->e1), e2 = ld3(T->e2);
     const V3 ro = v3(__shfl(ox, src), __shfl(oy, src), __shfl(oz, src));
     const V3 rd = v3(__shfl(dx, src), __shfl(dy, src), __shfl(dz, src));
@@ -368,7 +368,7 @@ __device__ __forceinline__ bool test_round(const SceneDev &S, const WalkJob &J, 
             hit_flag[src] = 1u;
         } else {
             // low word: visit rank of this leaf for this ray (see path_code), then the face's position in the leaf
-            atomicMin(&J.best[rref], key | (unsigned long long)((T->code ^ near_upper_levels(rd)) << 2));
+            atomicMin(&J.best[rref], key | (unsigned long long)((S.ltag[first].code ^ near_upper_levels(rd)) << 2));
         }
     }
     bool mine = false;
@@ -663,15 +663,24 @@ struct Surface {
 
 // Rebuilds what the shader holds in HitInfo after the closest-hit search from the compact hit record.
 // Re-running the winning analytic test reproduces its normal and object-space point bit for bit.
-// `known`: the winning triangle's record if the caller holds it already (same values as S.tris[face]; spares a gather).
+// `known`, `known_mat`: the winning triangle's edges and material if the caller holds them already (same values as
+// S.tris[face]; spares a gather).
 __device__ __forceinline__ bool make_surface(const SceneDev &S, V3 ro, V3 rd, float t, uint32_t hp, int32_t face, Surface &sf,
-                                             const TriDev *known = nullptr) {
+                                             const TriGeo *known = nullptr, int32_t known_mat = 0) {
     const uint32_t best = hp & 0xffffu, last = hp >> 16;
     if (face < 0 && best == 0xffffu) return false;
     sf.point = ro + rd * t;
     if (face >= 0) {
-        const TriDev &T = known ? *known : S.tris[face];
-        sf.normal = normalize(cross(ld3(T.e1), ld3(T.e2)));
+        V3 e1, e2;
+        if (known) {
+            e1 = ld3(known->e1); e2 = ld3(known->e2);
+            sf.mat = known_mat;
+        } else {
+            const TriDev &F = S.tris[face];
+            e1 = ld3(F.e1); e2 = ld3(F.e2);
+            sf.mat = F.mat;
+        }
+        sf.normal = normalize(cross(e1, e2));
         // intersectTriangle never writes localHitPoint (js/8-kd_tree.js:954): the shader still holds the
         // object-space point of the last analytic test that succeeded for this ray (zero if none did)
         sf.local = v3(0, 0, 0);
@@ -680,7 +689,6 @@ __device__ __forceinline__ bool make_surface(const SceneDev &S, V3 ro, V3 rd, fl
             hit_prim(S, S.prims[last], ro, rd, h);
             sf.local = h.loc;
         }
-        sf.mat = T.mat;
         sf.hit_id = S.n_prims + face;
     } else {
         PHit h;
@@ -715,21 +723,25 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
     // mesh hit of the closest-hit walk: it replaces the analytic hit only if strictly nearer (js/8-kd_tree.js:948-949)
     float ht = A.cur.ht[i];
     int32_t hf = A.cur.hf[i];
-    const TriDev *winner = nullptr;
+    const TriGeo *winner = nullptr;
+    int32_t winner_mat = 0;
     if (active) {
         const unsigned long long key = A.cur.best[i];
         if (key != ~0ull && __uint_as_float((uint32_t)(key >> 32)) < ht) {
             const uint32_t kr = (uint32_t)key;
-            const TriDev &T = S.ltris[S.path_slot[(kr >> 2) ^ near_upper_levels(rd)] + (kr & 3u)];
+            const uint32_t slot = S.path_slot[(kr >> 2) ^ near_upper_levels(rd)] + (kr & 3u);
+            const TriGeo &T = S.lgeo[slot];
+            const TriTag tag = S.ltag[slot];
             hit_tri(T, S.tri_eps, ro, rd, ht);   // the winner's exact t (the key folds -0 onto +0)
-            hf = T.face;
+            hf = tag.face;
             winner = &T;
+            winner_mat = tag.mat;
             A.cur.ht[i] = ht;
             A.cur.hf[i] = hf;
         }
     }
     Surface sf;
-    const bool hit = active && make_surface(S, ro, rd, ht, hp, hf, sf, winner);
+    const bool hit = active && make_surface(S, ro, rd, ht, hp, hf, sf, winner, winner_mat);
     if (in_range && !hit) {
         V3 c = active ? ld3(S.bg) : v3(0, 0, 0);
         A.cur.cr[tid] = c.x; A.cur.cg[tid] = c.y; A.cur.cb[tid] = c.z;
