@@ -32,3 +32,8 @@ node $H --script $K8 --model models/bun_zipper_res4.ply --depth 3 \
 # (js/8-kd_tree.js:2718-2792); the arrays and the tree are those of the frame after the drag
 node $H --script $K8 --model models/bun_zipper_res4.ply --depth 3 --mesh-material 0.7,0.6,0.7,16,0.3,0.5,0.9 \
      --drag 330,40,335,120,330,200 --out $G/k8_res4_drag_640x480
+# N3: camera controls. Mouse events delivered to the listeners the reference's THREE.TrackballControls registered (a pan
+# with the right button, a rotation with the left one, a wheel zoom), a tick after each; the camera is recorded per tick
+node $H --script $K8 --model models/bun_zipper_res4.ply \
+     --trackball "down:2:20:20,move:24:22,tick,up:24:22,tick,tick,down:0:20:20,move:22:21,tick,move:23:23,tick,up:23:23,tick,tick,wheel:-100,tick,tick" \
+     --out $G/k8_res4_trackball_640x480

@@ -23,6 +23,9 @@
  *              the reference only ever loads one mesh), so THIS HARNESS adds the mesh's first vertex index to
  *              its faces afterwards - the one step that is not the reference's own code.
  *        [--drag x0,y0,x1,y1]  drives ui.mouseDown(x0,y0), ui.mouseMove(x1,y1), ui.mouseUp(x1,y1)
+ *        [--trackball steps]   camera controls: DOM events delivered to the listeners the reference's
+ *                              THREE.TrackballControls registered on the canvas, and ticks in between; steps is a
+ *                              comma list of down:button:x:y | move:x:y | up:x:y | wheel:deltaY | tick
  *              (js/8-kd_tree.js:2718-2792) after the first tick and records what was picked and how the
  *              picked object's transform changed; a further tick then renders the moved scene
  */
@@ -37,7 +40,7 @@ const REF = process.env.RT_REFERENCE || '/root/reference';
 function parseArgs(argv) {
     const a = { script: '8-kd_tree.js', width: 640, height: 480, time: 0, sets: {}, fullArrays: false,
                 pixelPattern: 'lcg', out: null, ticks: 1,
-                meshMaterial: null, extraObj: null, extraScale: 1, extraTranslate: [0, 0, 0], drag: null };
+                meshMaterial: null, extraObj: null, extraScale: 1, extraTranslate: [0, 0, 0], drag: null, trackball: null };
     for (let i = 2; i < argv.length; i++) {
         const k = argv[i];
         if (k === '--script') a.script = argv[++i];
@@ -56,6 +59,7 @@ function parseArgs(argv) {
         else if (k === '--extra-scale') a.extraScale = +argv[++i];
         else if (k === '--extra-translate') a.extraTranslate = argv[++i].split(',').map(Number);
         else if (k === '--drag') a.drag = argv[++i].split(',').map(Number);
+        else if (k === '--trackball') a.trackball = argv[++i].split(',');
         else if (k === '--set') { const [n, v] = argv[++i].split('='); a.sets[n] = v; }
         else throw new Error('unknown arg ' + k);
     }
@@ -92,18 +96,21 @@ const gl = new Proxy(glTarget, {
 });
 
 // ---- stub DOM ----------------------------------------------------------------------
+// listeners by event type: TrackballControls registers its handlers on the canvas and, while a button is down, on the document
+const canvasListeners = {}, documentListeners = {};
 const canvas = {
     clientWidth: args.width, clientHeight: args.height, width: args.width, height: args.height,
     getContext: (kind) => (kind === 'webgl2' || kind === 'experimental-webgl' || kind === 'webgl') ? gl : null,
-    addEventListener() {}, style: {},
+    addEventListener(type, fn) { (canvasListeners[type] = canvasListeners[type] || []).push(fn); }, removeEventListener() {}, style: {},
     getBoundingClientRect: () => ({ left: 0, top: 0, width: args.width, height: args.height }),
     ownerDocument: null,
 };
 const document = {
     getElementById: () => canvas,
     body: { appendChild() {}, scrollLeft: 0, scrollTop: 0 },
-    documentElement: { scrollLeft: 0, scrollTop: 0 },
-    addEventListener() {}, removeEventListener() {},
+    documentElement: { scrollLeft: 0, scrollTop: 0, clientLeft: 0, clientTop: 0 },
+    addEventListener(type, fn) { (documentListeners[type] = documentListeners[type] || []).push(fn); },
+    removeEventListener(type, fn) { const l = documentListeners[type] || [], i = l.indexOf(fn); if (i >= 0) l.splice(i, 1); },
     createElement: () => ({ style: {}, appendChild() {}, addEventListener() {}, getContext: () => null }),
     createElementNS: () => ({ style: {} }),
 };
@@ -118,6 +125,7 @@ const sandbox = {
     Int16Array, Int32Array, DataView, Promise, Date, Math, Number, String, Array, Object, JSON,
     Error, parseFloat, parseInt, isNaN, Symbol, RegExp,
     performance: { now: () => 0 },
+    pageXOffset: 0, pageYOffset: 0, innerWidth: args.width, innerHeight: args.height,
 };
 sandbox.window = sandbox;
 sandbox.self = sandbox;
@@ -246,6 +254,38 @@ setImmediate(() => {
         vm.runInContext('tick(' + (args.time + 0.5) + ')', sandbox);
     }
 
+    let trackballRecord = null;
+    if (args.trackball) {
+        // the page's own canvas.onmousedown / onmousemove / onmouseup (js/8-kd_tree.js:3056-3088) get the event first, as
+        // in a browser (they call ui.mouseDown etc.; over the background nothing is selected and the controls stay enabled)
+        const pose = () => get(`({ position: [camera.position.x, camera.position.y, camera.position.z],
+            up: [camera.up.x, camera.up.y, camera.up.z],
+            quaternion: [camera.quaternion.x, camera.quaternion.y, camera.quaternion.z, camera.quaternion.w],
+            matrixWorld: Array.from(camera.matrixWorld.elements),
+            viewProjection: Array.from(ui.renderer.viewProjection.elements),
+            target: [ui.controls.target.x, ui.controls.target.y, ui.controls.target.z] })`);
+        const fire = (type, ev) => {
+            ev.type = type; ev.preventDefault = () => {}; ev.stopPropagation = () => {};
+            ev.clientX = ev.pageX; ev.clientY = ev.pageY;
+            const on = canvas['on' + type];
+            if (on) on(ev);
+            for (const fn of (canvasListeners[type] || []).slice()) fn(ev);
+            for (const fn of (documentListeners[type] || []).slice()) fn(ev);
+        };
+        trackballRecord = { steps: args.trackball, frames: [], start: pose() };
+        let t = args.time, lastX = 0, lastY = 0;
+        for (const step of args.trackball) {
+            const f = step.split(':');
+            if (f[0] === 'down') { lastX = +f[2]; lastY = +f[3]; fire('mousedown', { button: +f[1], pageX: lastX, pageY: lastY }); }
+            else if (f[0] === 'move') { lastX = +f[1]; lastY = +f[2]; fire('mousemove', { pageX: lastX, pageY: lastY }); }
+            else if (f[0] === 'up') { lastX = +f[1]; lastY = +f[2]; fire('mouseup', { pageX: lastX, pageY: lastY }); }
+            else if (f[0] === 'wheel') fire('wheel', { deltaY: +f[1], deltaMode: 0, pageX: lastX, pageY: lastY });
+            else if (f[0] === 'tick') { t += 1 / 60; vm.runInContext('tick(' + t + ')', sandbox); trackballRecord.frames.push(pose()); }
+            else throw new Error('unknown trackball step ' + step);
+        }
+        trackballRecord.last_time = t;
+    }
+
     fs.mkdirSync(args.out, { recursive: true });
     const sha = (buf) => crypto.createHash('sha256').update(Buffer.from(buf.buffer, buf.byteOffset, buf.byteLength)).digest('hex');
     const writeBin = (name, ta) => fs.writeFileSync(path.join(args.out, name), Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength));
@@ -324,6 +364,7 @@ setImmediate(() => {
         Lbar: rt ? rt.Lbar : null, sf: rt ? rt.sf : null,
         first_vert_f64: nV ? [v64[0], v64[1], v64[2]] : null,
         drag: dragRecord,
+        trackball: trackballRecord,
     };
 
     if (rt && rt.kdTree) {

@@ -56,14 +56,14 @@ function makeSceneAPI(G, THREE) {
     // unit shapes in object space (js/8-kd_tree.js:1267-1537)
     class Plane extends Primitive {
         constructor(id) { super(id); this.kind = PLANE; }
-        getMinCorner() { return new THREE.Vector3(-G.INFINITY, 0, -G.INFINITY); }
-        getMaxCorner() { return new THREE.Vector3(G.INFINITY, 0, G.INFINITY); }
+        getMinCorner() { return new THREE.Vector3(-10, -10, -10); }   // the handle a plane is selected and grabbed by (js/8-kd_tree.js:1279-1285)
+        getMaxCorner() { return new THREE.Vector3(10, 10, 10); }
         scale(scale) { throw new Error("Plane: cannot call abstract method 'scale'"); }
     }
     class Rectangle extends Primitive {
         constructor(id) { super(id); this.kind = RECT; }
-        getMinCorner() { return new THREE.Vector3(-0.5, 0, -0.5); }
-        getMaxCorner() { return new THREE.Vector3(0.5, 0, 0.5); }
+        getMinCorner() { return new THREE.Vector3(-0.5, -10, -0.5); }   // js/8-kd_tree.js:1324-1330
+        getMaxCorner() { return new THREE.Vector3(0.5, 10, 0.5); }
     }
     class Sphere extends Primitive {
         constructor(id) { super(id); this.kind = SPHERE; }

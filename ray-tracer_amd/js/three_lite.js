@@ -2,7 +2,107 @@
 // The few three.js r84 types the scene-description API of the reference touches (js/8-kd_tree.js:1094-1098,
 // :1180-1181, :1245-1257, :2055-2096, :2674, :2934-3022), with r84's mixed precision: Matrix4 elements live in a
 // Float32Array (every store rounds to single precision), Vector3 components and all arithmetic are doubles.
+// Vector2, Quaternion, EventDispatcher and the camera's position / quaternion / lookAt pose are what three.js's own
+// examples/js/controls/TrackballControls.js needs (the reference's UI creates one, js/8-kd_tree.js:2680-2688): that
+// file runs unchanged against this module.
 // No WebGL, no DOM: this is all of "THREE" that the render path needs.
+
+class Vector2 {
+    constructor(x, y) {
+        this.x = x || 0;
+        this.y = y || 0;
+    }
+    set(x, y) { this.x = x; this.y = y; return this; }
+    clone() { return new Vector2(this.x, this.y); }
+    copy(v) { this.x = v.x; this.y = v.y; return this; }
+    add(v) { this.x += v.x; this.y += v.y; return this; }
+    sub(v) { this.x -= v.x; this.y -= v.y; return this; }
+    subVectors(a, b) { this.x = a.x - b.x; this.y = a.y - b.y; return this; }
+    multiplyScalar(s) {
+        if (isFinite(s)) { this.x *= s; this.y *= s; } else { this.x = 0; this.y = 0; }
+        return this;
+    }
+    lengthSq() { return this.x * this.x + this.y * this.y; }
+    length() { return Math.sqrt(this.x * this.x + this.y * this.y); }
+    distanceToSquared(v) { const dx = this.x - v.x, dy = this.y - v.y; return dx * dx + dy * dy; }
+    equals(v) { return v.x === this.x && v.y === this.y; }
+}
+
+class Quaternion {
+    constructor(x, y, z, w) {
+        this.x = x || 0;
+        this.y = y || 0;
+        this.z = z || 0;
+        this.w = w !== undefined ? w : 1;
+    }
+    set(x, y, z, w) { this.x = x; this.y = y; this.z = z; this.w = w; return this; }
+    clone() { return new Quaternion(this.x, this.y, this.z, this.w); }
+    copy(q) { this.x = q.x; this.y = q.y; this.z = q.z; this.w = q.w; return this; }
+    // axis must be normalised
+    setFromAxisAngle(axis, angle) {
+        const half = angle / 2, s = Math.sin(half);
+        this.x = axis.x * s;
+        this.y = axis.y * s;
+        this.z = axis.z * s;
+        this.w = Math.cos(half);
+        return this;
+    }
+    // the upper 3x3 of m must be a pure rotation; branch order and expressions as in r84
+    setFromRotationMatrix(m) {
+        const te = m.elements;
+        const m11 = te[0], m12 = te[4], m13 = te[8], m21 = te[1], m22 = te[5], m23 = te[9], m31 = te[2], m32 = te[6], m33 = te[10];
+        const trace = m11 + m22 + m33;
+        let s;
+        if (trace > 0) {
+            s = 0.5 / Math.sqrt(trace + 1.0);
+            this.w = 0.25 / s;
+            this.x = (m32 - m23) * s;
+            this.y = (m13 - m31) * s;
+            this.z = (m21 - m12) * s;
+        } else if (m11 > m22 && m11 > m33) {
+            s = 2.0 * Math.sqrt(1.0 + m11 - m22 - m33);
+            this.w = (m32 - m23) / s;
+            this.x = 0.25 * s;
+            this.y = (m12 + m21) / s;
+            this.z = (m13 + m31) / s;
+        } else if (m22 > m33) {
+            s = 2.0 * Math.sqrt(1.0 + m22 - m11 - m33);
+            this.w = (m13 - m31) / s;
+            this.x = (m12 + m21) / s;
+            this.y = 0.25 * s;
+            this.z = (m23 + m32) / s;
+        } else {
+            s = 2.0 * Math.sqrt(1.0 + m33 - m11 - m22);
+            this.w = (m21 - m12) / s;
+            this.x = (m13 + m31) / s;
+            this.y = (m23 + m32) / s;
+            this.z = 0.25 * s;
+        }
+        return this;
+    }
+}
+
+class EventDispatcher {
+    addEventListener(type, listener) {
+        if (this._listeners === undefined) this._listeners = {};
+        const l = this._listeners;
+        if (l[type] === undefined) l[type] = [];
+        if (l[type].indexOf(listener) === -1) l[type].push(listener);
+    }
+    hasEventListener(type, listener) {
+        return this._listeners !== undefined && this._listeners[type] !== undefined && this._listeners[type].indexOf(listener) !== -1;
+    }
+    removeEventListener(type, listener) {
+        if (this._listeners === undefined || this._listeners[type] === undefined) return;
+        const i = this._listeners[type].indexOf(listener);
+        if (i !== -1) this._listeners[type].splice(i, 1);
+    }
+    dispatchEvent(event) {
+        if (this._listeners === undefined || this._listeners[event.type] === undefined) return;
+        event.target = this;
+        for (const f of this._listeners[event.type].slice()) f.call(this, event);
+    }
+}
 
 class Vector3 {
     constructor(x, y, z) {
@@ -67,6 +167,20 @@ class Vector3 {
         return this.applyMatrix4(m);
     }
     equals(v) { return v.x === this.x && v.y === this.y && v.z === this.z; }
+    setLength(l) { return this.multiplyScalar(l / this.length()); }
+    distanceToSquared(v) { const dx = this.x - v.x, dy = this.y - v.y, dz = this.z - v.z; return dx * dx + dy * dy + dz * dz; }
+    // q * v * q^-1, products in r84's order
+    applyQuaternion(q) {
+        const x = this.x, y = this.y, z = this.z, qx = q.x, qy = q.y, qz = q.z, qw = q.w;
+        const ix = qw * x + qy * z - qz * y;
+        const iy = qw * y + qz * x - qx * z;
+        const iz = qw * z + qx * y - qy * x;
+        const iw = -qx * x - qy * y - qz * z;
+        this.x = ix * qw + iw * -qx + iy * -qz - iz * -qy;
+        this.y = iy * qw + iw * -qy + iz * -qx - ix * -qz;
+        this.z = iz * qw + iw * -qz + ix * -qy - iy * -qx;
+        return this;
+    }
     toArray(out, offset) {
         out = out || [];
         offset = offset || 0;
@@ -113,6 +227,38 @@ class Matrix4 {
         r[15] = 1;
         return this._put(r);
     }
+    makeRotationFromQuaternion(q) {
+        const x = q.x, y = q.y, z = q.z, w = q.w;
+        const x2 = x + x, y2 = y + y, z2 = z + z;
+        const xx = x * x2, xy = x * y2, xz = x * z2, yy = y * y2, yz = y * z2, zz = z * z2, wx = w * x2, wy = w * y2, wz = w * z2;
+        return this._put([1 - (yy + zz), xy + wz, xz - wy, 0, xy - wz, 1 - (xx + zz), yz + wx, 0, xz + wy, yz - wx, 1 - (xx + yy), 0, 0, 0, 0, 1]);
+    }
+    // rotation part only (the other elements stay): z = eye - target, x = up x z, y = z x x
+    lookAt(eye, target, up) {
+        const z = new Vector3().subVectors(eye, target).normalize();
+        if (z.lengthSq() === 0) z.z = 1;
+        const x = new Vector3().crossVectors(up, z).normalize();
+        if (x.lengthSq() === 0) {
+            z.z += 0.0001;
+            x.crossVectors(up, z).normalize();
+        }
+        const y = new Vector3().crossVectors(z, x);
+        const te = this.elements;
+        te[0] = x.x; te[4] = y.x; te[8] = z.x;
+        te[1] = x.y; te[5] = y.y; te[9] = z.y;
+        te[2] = x.z; te[6] = y.z; te[10] = z.z;
+        return this;
+    }
+    scale(v) {
+        const te = this.elements, x = v.x, y = v.y, z = v.z;
+        te[0] *= x; te[4] *= y; te[8] *= z;
+        te[1] *= x; te[5] *= y; te[9] *= z;
+        te[2] *= x; te[6] *= y; te[10] *= z;
+        te[3] *= x; te[7] *= y; te[11] *= z;
+        return this;
+    }
+    setPosition(v) { const te = this.elements; te[12] = v.x; te[13] = v.y; te[14] = v.z; return this; }
+    compose(position, quaternion, scale) { return this.makeRotationFromQuaternion(quaternion).scale(scale).setPosition(position); }
     multiply(m) { return this.multiplyMatrices(this, m); }
     premultiply(m) { return this.multiplyMatrices(m, this); }
     multiplyMatrices(A, B) {
@@ -183,9 +329,10 @@ class Matrix4 {
 
 const DEG2RAD = Math.PI / 180;
 
-// Pose = matrixWorld. The reference leaves the camera where TrackballControls.reset() puts it: at the origin,
-// looking down -z (js/8-kd_tree.js:2798-2802), so matrixWorld starts as the identity; callers that move the
-// camera set position and matrixWorld themselves (lookAt below).
+// The pose is position + quaternion (+ scale) as in three.js's Object3D; updateMatrixWorld() composes matrixWorld from
+// them with r84's arithmetic (quaternion -> single-precision rotation matrix). The reference leaves the camera where
+// TrackballControls.reset() puts it, at the origin looking down -z (js/8-kd_tree.js:2798-2802): matrixWorld starts as
+// the identity.
 class PerspectiveCamera {
     constructor(fov, aspect, near, far) {
         this.fov = fov !== undefined ? fov : 50;
@@ -194,10 +341,14 @@ class PerspectiveCamera {
         this.far = far !== undefined ? far : 2000;
         this.zoom = 1;
         this.position = new Vector3(0, 0, 0);
+        this.quaternion = new Quaternion();
+        this.scale = new Vector3(1, 1, 1);
         this.up = new Vector3(0, 1, 0);
+        this.matrix = new Matrix4();
         this.matrixWorld = new Matrix4();
         this.matrixWorldInverse = new Matrix4();
         this.projectionMatrix = new Matrix4();
+        this._look = new Matrix4();   // r84 keeps one scratch matrix for every lookAt: only its rotation part is ever written
         this.updateProjectionMatrix();
     }
     updateProjectionMatrix() {
@@ -208,19 +359,18 @@ class PerspectiveCamera {
         const left = -0.5 * width;
         this.projectionMatrix.makePerspective(left, left + width, top, top - height, near, this.far);
     }
-    // camera at `position` looking at `target`: rotation columns (x, y, z) with z pointing backwards, then the
-    // translation; matrixWorldInverse follows
+    // Camera.lookAt of r84: the orientation only; matrixWorld follows at the next updateMatrixWorld()
     lookAt(target) {
-        const z = new Vector3().subVectors(this.position, target).normalize();
-        if (z.lengthSq() === 0) z.z = 1;
-        let x = new Vector3().crossVectors(this.up, z).normalize();
-        if (x.lengthSq() === 0) { z.z += 0.0001; x = new Vector3().crossVectors(this.up, z).normalize(); }
-        const y = new Vector3().crossVectors(z, x);
-        this.matrixWorld._put([x.x, x.y, x.z, 0, y.x, y.y, y.z, 0, z.x, z.y, z.z, 0, this.position.x, this.position.y, this.position.z, 1]);
-        this.matrixWorldInverse.getInverse(this.matrixWorld);
+        this._look.lookAt(this.position, target, this.up);
+        this.quaternion.setFromRotationMatrix(this._look);
         return this;
     }
-    updateMatrixWorld() { this.matrixWorldInverse.getInverse(this.matrixWorld); }
+    updateMatrix() { this.matrix.compose(this.position, this.quaternion, this.scale); }
+    updateMatrixWorld() {
+        this.updateMatrix();
+        this.matrixWorld.copy(this.matrix);
+        this.matrixWorldInverse.getInverse(this.matrixWorld);
+    }
 }
 
-module.exports = { Vector3, Euler, Matrix4, PerspectiveCamera, Math: { DEG2RAD } };
+module.exports = { Vector2, Vector3, Quaternion, Euler, Matrix4, EventDispatcher, PerspectiveCamera, Math: { DEG2RAD } };

@@ -51,6 +51,110 @@ def test_unchanged_reference_generate_scene_runs(golden):
     assert out["failures"] == [] and out["scene"] == "page script"
 
 
+REF_CONTROLS = "/root/reference/js/controls/TrackballControls.js"
+
+
+@needs_node
+def test_js_camera_pose_after_trackball_moves_matches_reference():
+    """The fixture holds the camera after a pan, a rotation and a zoom done with the reference's THREE.TrackballControls
+    (recorded tick by tick). Without the controls file the recorded pose (position, up, quaternion) is taken over: the
+    camera matrix composed from it, cameraPos and the four corner rays must equal what the reference handed to WebGL."""
+    out = run_node([os.path.join(JS, "test", "check_golden.js"), os.path.join(GOLDEN, "k8_res4_trackball_640x480")])
+    assert out["failures"] == [] and out["uniforms_checked"] >= 80 and out["controls_replayed"] is False
+
+
+@needs_node
+@pytest.mark.skipif(not os.path.exists(REF_CONTROLS), reason="reference checkout not present")
+def test_unchanged_trackball_controls_run_on_three_lite():
+    """three.js's own TrackballControls.js, read from the reference checkout at test time and evaluated as it is
+    against three_lite.js and the event surfaces of ui.js: the recorded mouse events replayed through UI.handleEvent
+    must leave the camera exactly where the reference's camera was after every tick (position, up, quaternion,
+    matrixWorld, view-projection, controls target - all compared with ==)."""
+    out = run_node([os.path.join(JS, "test", "check_golden.js"), os.path.join(GOLDEN, "k8_res4_trackball_640x480"), "-", REF_CONTROLS])
+    assert out["failures"] == [] and out["controls_replayed"] is True
+
+
+@needs_node
+def test_js_selection_box_of_the_dragged_mesh():
+    """Renderer.render() draws the selected object's box with a line program (js/8-kd_tree.js:2646-2664); its uniforms
+    after the drag are in the fixture (checked with == inside check_golden.js). Here the edges the rasteriser draws are
+    checked against an independent projection of the eight corners: every end point of a visible edge is a projected
+    corner or lies on the canvas border (the box sticks out at the top after the drag), and lines were drawn."""
+    from helpers import manifest
+    m = manifest("k8_res4_drag_640x480")
+    out = run_node([os.path.join(JS, "test", "check_golden.js"), os.path.join(GOLDEN, "k8_res4_drag_640x480")])
+    assert out["failures"] == []
+    u = {x["name"]: np.array(x["value"], np.float64) for x in m["uniforms"]}
+    mvp = u["modelViewProjection"].reshape(4, 4).T   # column-major
+    corners = []
+    for c in range(8):
+        t = np.array([c & 1, (c >> 1) & 1, c >> 2], np.float64)
+        p = mvp @ np.append(u["cubeMin"] * (1 - t) + u["cubeMax"] * t, 1.0)
+        corners.append(((p[0] / p[3] * 0.5 + 0.5) * m["width"], (1 - (p[1] / p[3] * 0.5 + 0.5)) * m["height"]))
+    corners = np.array(corners)
+    segs = np.array(out["selection_segments"])
+    assert 1 <= len(segs) <= 12 and out["selection_pixels"] > 100
+    for x, y in segs.reshape(-1, 2):
+        on_corner = np.min(np.hypot(corners[:, 0] - x, corners[:, 1] - y)) < 1e-2
+        on_border = min(abs(x), abs(y), abs(x - m["width"]), abs(y - m["height"])) < 1e-6
+        assert on_corner or on_border, (x, y)
+
+
+@pytest.mark.skipif(NODE is None, reason="node is missing")
+def test_js_png_writer_is_read_back_by_an_independent_decoder(tmp_path):
+    """png.js (the frames examples/serve.js streams to a browser): chunk CRCs and the zlib stream are checked here with
+    Python's zlib, the pixels against the pattern the script wrote (rows bottom-up in, top-down in the file)."""
+    import struct
+    import zlib
+    out = tmp_path / "t.png"
+    code = r"""
+const { encodePNG, decodePNG } = require(%r);
+const W = 37, H = 11, p = new Uint8Array(W * H * 4);
+for (let i = 0; i < p.length; i++) p[i] = (i * 37 + (i >> 3)) & 255;
+const b = encodePNG(p, W, H, true);
+require('fs').writeFileSync(%r, b);
+const d = decodePNG(b);
+let ok = d.width === W && d.height === H;
+for (let y = 0; y < H; y++) for (let i = 0; i < W * 4; i++) if (d.pixels[y * W * 4 + i] !== p[(H - 1 - y) * W * 4 + i]) ok = false;
+console.log(JSON.stringify({ ok }));
+""" % (os.path.join(JS, "png.js"), str(out))
+    assert run_node(["-e", code])["ok"] is True
+    b = out.read_bytes()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, size = 8, b"", None
+    while pos < len(b):
+        n, typ = struct.unpack(">I4s", b[pos:pos + 8])
+        data = b[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + data)
+        if typ == b"IHDR":
+            size = struct.unpack(">IIBBBBB", data)
+        elif typ == b"IDAT":
+            idat += data
+        pos += 12 + n
+    assert size == (37, 11, 8, 6, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(11, 37 * 4 + 1)
+    assert (raw[:, 0] == 0).all()
+    i = np.arange(37 * 11 * 4)
+    want = ((i * 37 + (i >> 3)) & 255).astype(np.uint8).reshape(11, 37 * 4)[::-1]
+    assert np.array_equal(raw[:, 1:], want)
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_serve_streams_frames_and_takes_events():
+    """examples/serve.js --self-test: the page, /frame.png, /event and /stream exercised over HTTP on 127.0.0.1 by a
+    client in the same process. A click on the glass sphere selects it (picked from the hit-id buffer) and the next
+    frame differs from the plain one by white overlay pixels only; a second press grabs, a move drags, and the frames
+    the server sends equal what UI.render() returns."""
+    out = run_node([os.path.join(JS, "examples", "serve.js"), "--self-test", "--width", "320", "--height", "240", "--depth", "2"])
+    assert out["page_ok"] and out["frame_size"] == [320, 240] and out["plain_frame_equals_direct_render"]
+    assert out["selected"] == "Sphere" and out["overlay_pixels"] > 100 and out["pixels_changed_by_overlay_only"]
+    assert out["selection_segments"] == 12
+    assert out["grabbed"] is True and out["moved_x"] > 0
+    assert out["frame_after_drag_differs"] and out["frame_after_drag_equals_direct_render"] and out["stream_first_part_png"]
+    assert out["bad_event_status"] == 400
+
+
 @needs_node
 def test_js_abstract_classes_and_errors():
     code = r"""

@@ -1,12 +1,11 @@
 #!/usr/bin/env python3
-"""Renders one frame through the C ABI and writes the presented canvas as a PNG (zlib only, no imaging library).
-  python tools/render.py --out frame.png [--width 1280 --height 720 --depth 5 --ss 1 --tr 0 --time 0 --model bun_zipper.ply
-                                          --teapot 1 --reflective 1 --kd-builder device]"""
+"""Renders one frame through the C ABI and writes the presented canvas as a PNG and, with --exr, the float render target
+(before tone reproduction) as an OpenEXR file (standard library only, no imaging library).
+  python tools/render.py --out frame.png [--exr frame.exr] [--width 1280 --height 720 --depth 5 --ss 1 --tr 0 --time 0
+                                          --model bun_zipper.ply --teapot 1 --reflective 1 --kd-builder device]"""
 import argparse
 import os
-import struct
 import sys
-import zlib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,23 +13,13 @@ import rt_loader  # noqa: E402
 
 rt_loader.load()
 from ray_tracer_amd import abi, scene  # noqa: E402
-
-
-def write_png(path, rgba_bottom_up):
-    h, w, _ = rgba_bottom_up.shape
-    rows = rgba_bottom_up[::-1, :, :3]                      # PNG rows run top-down, the canvas bottom-up (gl.readPixels order)
-    raw = b"".join(b"\x00" + rows[y].tobytes() for y in range(h))
-
-    def chunk(tag, data):
-        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
-    with open(path, "wb") as f:
-        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
-                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+from ray_tracer_amd.image_io import write_exr, write_png  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
+    ap.add_argument("--exr", default=None, help="also write the float render target (supersampled size) as OpenEXR")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--depth", type=int, default=5)
@@ -53,6 +42,8 @@ def main():
     rt.trace()
     Lbar, sf = rt.tone()
     write_png(a.out, rt.present())
+    if a.exr:
+        write_exr(a.exr, rt.readFloat()[:, :, :3])
     st = rt.stats()
     print("%s: %dx%d, %d rays, trace %.2f ms, Lbar %.4f sf %.4f" % (a.out, a.width, a.height, st.rays_total, st.trace_ms, Lbar, sf))
 
