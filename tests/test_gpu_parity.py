@@ -8,9 +8,9 @@ reduction sums in a different order."""
 import numpy as np
 import pytest
 
-from helpers import device_canvas, make_flat, manifest, sha
+from helpers import device_canvas, make_flat, manifest, model, sha
 from oracle import oracle
-from ray_tracer_amd import abi
+from ray_tracer_amd import abi, scene
 
 pytestmark = pytest.mark.gpu
 TONE_RTOL = 1e-10
@@ -113,6 +113,23 @@ def test_odd_frame_rays_with_zero_direction_components():
     flat = make_flat("bun_zipper_res3.ply", 321, 241, depth=3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
     rt, o, (gf, g8, gid), cn = check_against_oracle(flat)
     assert rt.stats().rays_total == cn.rays
+
+
+def test_moved_camera_pose_from_the_reference_controls():
+    """The camera after a pan, a rotation and a wheel zoom with the reference's TrackballControls (fixture
+    k8_res4_trackball_640x480: cameraPos and the four corner rays as the reference handed them to WebGL): the corner
+    rays are no longer symmetric and the camera no longer sits at the origin. Depth 3 with the reflective mesh."""
+    from helpers import manifest
+    m = manifest("k8_res4_trackball_640x480")
+    last = {}
+    for u in m["uniforms"]:
+        last[u["name"]] = u["value"]
+    cam = {k: np.array(last[k], np.float32) for k in ("cameraPos", "ray00", "ray01", "ray10", "ray11")}
+    assert np.abs(cam["cameraPos"]).max() > 10.0 and not np.allclose(cam["ray00"][:2], -cam["ray11"][:2])
+    sc = scene.default_scene(model("bun_zipper_res4.ply"), mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    scene.animate_light(sc, m["trackball"]["last_time"])
+    flat = abi.FlatScene(sc, abi.default_config(640, 480, depth=3), cam)
+    check_against_oracle(flat)
 
 
 def test_kdtree_export_through_gpu_context():
