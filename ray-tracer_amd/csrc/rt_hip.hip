@@ -493,6 +493,13 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     if (cfg->max_kd_depth < 1) { g_create_error = "rt_create: max_kd_depth must be >= 1"; return -1; }
     int sc = cfg->shard_count <= 1 ? 1 : cfg->shard_count;
     if (cfg->shard_index < 0 || cfg->shard_index >= sc) { g_create_error = "rt_create: shard_index out of range"; return -1; }
+    {   // tile numbers and ray indices are 32-bit: the supersampled render target may have at most 2^30 pixels
+        const uint64_t w = (uint64_t)cfg->width * (uint64_t)cfg->supersampling, h = (uint64_t)cfg->height * (uint64_t)cfg->supersampling;
+        const uint64_t blocks = ((w + 127) / 128) * ((h + 127) / 128);
+        if (w > (1u << 20) || h > (1u << 20) || blocks * 128 * 128 > (1ull << 30)) {
+            g_create_error = "rt_create: render target (width x height x supersampling^2) beyond 2^30 pixels"; return -1;
+        }
+    }
     if (cfg->device == -1) {   // host-only context: mesh + k-d build + export, nothing that touches a GPU
         rt_ctx *h = new rt_ctx();
         h->cfg = *cfg;
@@ -1273,6 +1280,11 @@ static int assemble_into(rt_ctx *ctx, const char *who, const void *gathered, siz
     if (ctx->host_only) return fail(ctx, (std::string(who) + ": host-only context (created with device = -1)").c_str());
     if (!gathered || n_shards < 1 || stride_bytes % 256) return fail(ctx, (std::string(who) + ": bad arguments").c_str());
     HIPCK(hipSetDevice(ctx->cfg.device));
+    // a shard of n_shards holds every n_shards-th tile: `stride` cannot be more than one tile beyond that, and the kernel
+    // indexes the gathered pixels with 32 bits
+    const uint64_t tiles_per_buffer = stride_bytes / 256;
+    if (tiles_per_buffer * (uint64_t)n_shards > (uint64_t)ctx->g.n_tiles + (uint64_t)n_shards || tiles_per_buffer * 64 * (uint64_t)n_shards >= (1ull << 32))
+        return fail(ctx, (std::string(who) + ": stride_bytes is larger than a shard of this frame").c_str());
     uint32_t stride = (uint32_t)(stride_bytes / 4);
     uint64_t total = (uint64_t)stride * (uint64_t)n_shards;
     hipLaunchKernelGGL(k_assemble, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)gathered,

@@ -261,6 +261,7 @@ def test_host_only_context_refuses_gpu_calls():
 
 
 def test_create_rejects_bad_config():
-    for kw in ({"width": 0}, {"max_depth": 0}, {"max_depth": 9}, {"supersampling": 0}, {"shard_index": 3, "shard_count": 2}):
+    for kw in ({"width": 0}, {"max_depth": 0}, {"max_depth": 9}, {"supersampling": 0}, {"shard_index": 3, "shard_count": 2},
+               {"width": 40000, "height": 40000}, {"width": 20000, "height": 20000, "supersampling": 2}):
         with pytest.raises(abi.RTError):
             abi.RayTracerHIP(abi.default_config(device=-1, **kw))
