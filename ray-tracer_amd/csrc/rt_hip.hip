@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -164,18 +165,20 @@ struct ToneScratch {
 };
 static __device__ __align__(256) unsigned char scratch[sizeof(ToneScratch)];
 constexpr int MAX_SCRATCH_DEVICES = 64;
-ToneScratch *g_scratch_ptr[MAX_SCRATCH_DEVICES] = {};   // device address of `scratch` on every GPU that has asked for it
+std::atomic<ToneScratch *> g_scratch_ptr[MAX_SCRATCH_DEVICES];   // device address of `scratch` on every GPU that has asked for it (zero-initialised; threads that race to fill an entry store the same address)
 
 // `scratch` names a host-side stand-in; the array's address on the CURRENT device comes from the runtime, once per device
 hipError_t scratch_on_current_device(int device, ToneScratch **out) {
     if (device < 0 || device >= MAX_SCRATCH_DEVICES) return hipErrorInvalidDevice;
-    if (!g_scratch_ptr[device]) {
+    ToneScratch *sp = g_scratch_ptr[device].load(std::memory_order_acquire);
+    if (!sp) {
         void *p = nullptr;
         const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
-        g_scratch_ptr[device] = (ToneScratch *)p;
+        sp = (ToneScratch *)p;
+        g_scratch_ptr[device].store(sp, std::memory_order_release);
     }
-    *out = g_scratch_ptr[device];
+    *out = sp;
     return hipSuccess;
 }
 

@@ -132,6 +132,103 @@ def test_moved_camera_pose_from_the_reference_controls():
     check_against_oracle(flat)
 
 
+def _random_scene(seed, with_mesh):
+    """Random primitives (every kind, every material type, reflective and transmissive ones among them) in front of a
+    randomly placed camera, one to three lights; optionally the small bunny under a random rotation and scale (a tree
+    nobody looked at before). Seeded: the same scenes every run."""
+    import math
+    from ray_tracer_amd.three_f32 import Euler, Vector3 as V
+    rng = np.random.default_rng(seed)
+    u = lambda a, b: float(rng.uniform(a, b))
+    sc = scene.Scene()
+    ids = sc.ids
+
+    def nid(name):
+        v = getattr(ids, name)
+        setattr(ids, name, v + 1)
+        return v
+
+    for _ in range(int(rng.integers(1, 4))):
+        sc.lights.append(scene.PointLight(nid("light"), V(u(-400, 400), u(50, 400), u(-500, 200)), V(u(0.2, 1), u(0.2, 1), u(0.2, 1))))
+    sc.n_lights_declared = ids.light
+    sc.ambientLight = V(u(0.2, 0.9), u(0.2, 0.9), u(0.2, 0.9))
+    sc.bgColor = V(u(0, 1), u(0, 1), u(0, 1))
+
+    def material():
+        kind = int(rng.integers(0, 3))
+        kr = u(0.2, 0.8) if rng.random() < 0.7 else 0.0
+        kt = u(0.3, 0.9) if rng.random() < 0.5 else 0.0
+        common = (u(0.05, 0.6), u(0.1, 0.9), u(0.1, 1.0), float(rng.integers(4, 40)), kr, kt, u(0.7, 1.6))
+        col = lambda: V(u(0, 1), u(0, 1), u(0, 1))
+        if kind == 0:
+            m = scene.Phong(nid("phong"), *common, col(), col())
+        elif kind == 1:
+            m = scene.PhongBlinn(nid("blinn"), *common, col(), col())
+        else:
+            m = scene.PhongCheckered(nid("checkered"), *common, col(), col(), col())
+        sc.materials.append(m)
+        return m
+
+    kinds = [scene.Sphere, scene.Cube, scene.Cylinder, scene.Rectangle, scene.Sphere, scene.Cube, scene.Cylinder]
+    rng.shuffle(kinds)
+    for cls in kinds[:int(rng.integers(3, 8))]:
+        o = cls(nid("object"))
+        if cls is scene.Rectangle:
+            o.scale(V(u(100, 600), 1, u(100, 900)))
+            o.rotate(Euler(u(-0.3, 0.3), u(-1, 1), u(-0.3, 0.3), "XYZ"))
+            o.translate(V(u(-100, 100), u(-120, -40), u(-400, -200)))
+        else:
+            o.scale(V(u(15, 70), u(15, 70), u(15, 70)))
+            o.rotate(Euler(u(-math.pi, math.pi), u(-math.pi, math.pi), u(-math.pi, math.pi), "XYZ"))
+            o.translate(V(u(-150, 150), u(-60, 120), u(-450, -150)))
+        o.setMaterial(material())
+        sc.objects.append(o)
+    if rng.random() < 0.5:   # an infinite plane far below
+        pl = scene.Plane(nid("object"))
+        pl.translate(V(0, u(-300, -150), 0))
+        pl.setMaterial(material())
+        sc.objects.append(pl)
+    if with_mesh:
+        v, f = scene.load_ply(model("bun_zipper_res4.ply"))
+        mesh = scene.Mesh(nid("object"), v, f, sc.meshes)
+        s = u(500, 1200)
+        mesh.scale(V(s, s, s))
+        mesh.rotate(Euler(u(-1, 1), u(-math.pi, math.pi), u(-1, 1), "XYZ"))
+        mesh.translate(V(u(-60, 60), u(-40, 60), u(-320, -200)))
+        mesh.setMaterial(material())
+        sc.objects.append(mesh)
+    # camera: somewhere in front of the scene, looking at its middle; corner rays of a 45 degree frustum in float32
+    eye = np.array([u(-120, 120), u(-20, 150), u(-60, 120)])
+    fwd = np.array([u(-40, 40), u(-20, 40), -270.0]) - eye
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, [0.0, 1.0, 0.0])
+    right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    th = math.tan(math.radians(22.5))
+    cam = {"cameraPos": eye.astype(np.float32)}
+    for name, (x, y) in {"ray00": (-1, -1), "ray01": (-1, 1), "ray10": (1, -1), "ray11": (1, 1)}.items():
+        d = fwd + right * (x * th * 1.5) + up * (y * th)
+        cam[name] = (d / np.linalg.norm(d)).astype(np.float32)
+    return sc, cam
+
+
+@pytest.mark.parametrize("seed", list(range(1, 25)))
+def test_random_scenes_match_the_oracle(seed):
+    """Scenes nobody tuned: random transforms (rotated cylinders and cubes, stretched spheres), random materials of the
+    three types, random lights and camera; every other scene holds the mesh, every fifth is supersampled, the recursion
+    depth runs through 2 .. 6, both tone operators. Everything `check_against_oracle` compares must be equal."""
+    with_mesh, ss = seed % 2 == 1, 2 if seed % 5 == 0 else 1
+    sc, cam = _random_scene(seed, with_mesh)
+    flat = abi.FlatScene(sc, abi.default_config(120, 80, depth=2 + seed % 5, supersampling=ss, tr_method=seed & 1), cam)
+    rt, o, (_, got_8, _), cn = check_against_oracle(flat)
+    assert cn.rays >= 120 * 80 * ss * ss
+    Lbar, sf = rt.tone()
+    oL, osf = o.tone(got_8)
+    assert abs(Lbar - oL) <= TONE_RTOL * abs(oL) and abs(sf - osf) <= 1e-8 * abs(osf)
+    assert np.array_equal(rt.present(), o.present(got_8, oL, osf))
+    rt.close()
+
+
 def test_kdtree_export_through_gpu_context():
     m = manifest("k8_res3_640x480")
     flat = make_flat("bun_zipper_res3.ply", 64, 48)
