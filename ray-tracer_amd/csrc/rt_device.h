@@ -18,7 +18,9 @@ constexpr int MAX_LEVELS = 8;
 
 struct PrimDev {
     int32_t kind, mat;            // mat = index into the material table (-1: none)
-    int32_t pad0, pad1;
+    float bound_r2;               // squared radius of a sphere round the model's origin (m[9..11]) that holds the
+                                  // primitive, with a margin (see surely_misses); 0 = unbounded (plane, rectangle)
+    int32_t pad1;
     float m[12];                  // model: columns 0..3, rows 0..2  (m[3*c + r])
     float im[12];                 // inverse model, same packing
 };
@@ -292,6 +294,24 @@ __device__ __forceinline__ bool hit_cylinder(const SceneDev &, const PrimDev &P,
         }
     }
     return false;
+}
+
+// True only if the ray's line passes the primitive's bounding sphere at a distance: by more than 1 % of the radius
+// (in bound_r2) plus 1 % of the distance between the ray's origin and the sphere's centre. The intersection routines
+// above then return false - also in float32: what separates hit from miss there (a discriminant, slab distances) is
+// then at least 1e-4 of the terms it is computed from, a thousand times their rounding error. Their results are
+// unchanged; a wave whose rays all pass the sphere skips the routine. A NaN or a zero direction never says "misses".
+// The cube's slab test treats an exactly zero direction component as an unbounded slab (0.5 / 0 - o / 0 = NaN, which
+// min and max drop) and can then report a hit far outside the cube: such rays are never filtered.
+__device__ __forceinline__ bool surely_misses(const PrimDev &P, V3 ro, V3 rd) {
+    const V3 v = v3(P.m[9] - ro.x, P.m[10] - ro.y, P.m[11] - ro.z);
+    const V3 cr = cross(v, rd);
+    bool far_off = P.bound_r2 > 0.0f && dot(cr, cr) > dot(rd, rd) * (P.bound_r2 + 1.0e-4f * dot(v, v));
+    if (P.kind == 3) {   // wave-uniform
+        const V3 ld = xdir(P.im, rd);
+        far_off = far_off && ld.x != 0.0f && ld.y != 0.0f && ld.z != 0.0f;
+    }
+    return far_off;
 }
 
 __device__ __forceinline__ bool hit_prim(const SceneDev &S, const PrimDev &P, V3 ro, V3 rd, PHit &h) {

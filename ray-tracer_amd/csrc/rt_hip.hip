@@ -302,9 +302,41 @@ int upload_scene(rt_ctx *ctx) {
         PrimDev &d = ctx->prims[i];
         d.kind = s.kind;
         d.mat = find_mat(s.mat_type, s.mat_id);
-        d.pad0 = d.pad1 = 0;
+        d.pad1 = 0;
         for (int c = 0; c < 4; c++)
             for (int r = 0; r < 3; r++) { d.m[3 * c + r] = s.model[4 * c + r]; d.im[3 * c + r] = s.inv_model[4 * c + r]; }
+        // bounding sphere round the model's origin: the farthest corner of the object-space box that holds the unit
+        // shape (sphere: radius 1; cube: half side 0.5; cylinder: radius 1, half height 0.5), 1 % added, rounded up
+        d.bound_r2 = 0.0f;
+        const double ext[5][3] = {{0, 0, 0}, {0, 0, 0}, {1, 1, 1}, {0.5, 0.5, 0.5}, {1, 0.5, 1}};
+        if (s.kind >= RT_PRIM_SPHERE && s.kind <= RT_PRIM_CYLINDER) {
+            double r2 = 0.0;
+            for (int corner = 0; corner < 8; corner++) {
+                double w[3] = {0, 0, 0};
+                for (int c = 0; c < 3; c++) {
+                    const double e = ((corner >> c) & 1 ? 1.0 : -1.0) * ext[s.kind][c];
+                    for (int r = 0; r < 3; r++) w[r] += (double)s.model[4 * c + r] * e;
+                }
+                r2 = std::max(r2, w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+            }
+            if (s.kind == RT_PRIM_SPHERE) {
+                // the unit sphere itself: its image lies within the largest singular value of the linear part, whose
+                // square is at most the largest absolute row sum of the Gram matrix (exact for a rotated uniform scale)
+                double g = 0.0;
+                for (int i = 0; i < 3; i++) {
+                    double row = 0.0;
+                    for (int j = 0; j < 3; j++) {
+                        double e = 0.0;
+                        for (int r = 0; r < 3; r++) e += (double)s.model[4 * i + r] * (double)s.model[4 * j + r];
+                        row += std::fabs(e);
+                    }
+                    g = std::max(g, row);
+                }
+                r2 = std::min(r2, g);
+            }
+            const double b = r2 * 1.0201 * 1.0001;
+            d.bound_r2 = (std::isfinite(b) && b < 1e30) ? (float)b : 0.0f;
+        }
     }
     ctx->mats.resize(ctx->mats_host.size());
     for (size_t i = 0; i < ctx->mats_host.size(); i++) {
@@ -831,19 +863,20 @@ static int launch_step(rt_ctx *ctx, Part &P, int k) {
         J.enabled = walk ? 1u : 0u;
     }
     (void)last;
-    const dim3 grid((A.n_rays + BLOCK - 1) / BLOCK), grid_prev((B.n_rays + BLOCK - 1) / BLOCK);
+    const uint32_t bs = shade_block(A.n_rays), bs_prev = shade_block(B.n_rays);
+    const dim3 grid((A.n_rays + bs - 1) / bs), grid_prev((B.n_rays + bs_prev - 1) / bs_prev);
     // persistent traversal waves: one 64-lane workgroup each (LDS: short stacks + mailbox)
     const dim3 walk_grid((unsigned)ctx->n_cus * (unsigned)ctx->walk_waves_per_cu);
     const bool any_walk = Wk.job[0].enabled || Wk.job[1].enabled;
     hipEvent_t *ev = P.ev[k];
     if (ctx->stage_timing) HIPCK(hipEventRecord(ev[0], s));
-    if (have_cur) hipLaunchKernelGGL(k_gen_prims, grid, dim3(BLOCK), 0, s, A);
+    if (have_cur) hipLaunchKernelGGL(k_gen_prims, grid, dim3(bs), 0, s, A);
     if (ctx->stage_timing) HIPCK(hipEventRecord(ev[1], s));
     if (any_walk) hipLaunchKernelGGL(k_kd_walk, walk_grid, dim3(WAVE), 0, s, Wk);
     if (ctx->stage_timing) HIPCK(hipEventRecord(ev[2], s));
-    if (have_prev) hipLaunchKernelGGL(k_shade_b, grid_prev, dim3(BLOCK), 0, s, B);
+    if (have_prev) hipLaunchKernelGGL(k_shade_b, grid_prev, dim3(bs_prev), 0, s, B);
     if (ctx->stage_timing) HIPCK(hipEventRecord(ev[3], s));
-    if (have_cur) hipLaunchKernelGGL(k_shade_a, grid, dim3(BLOCK), 0, s, A);
+    if (have_cur) hipLaunchKernelGGL(k_shade_a, grid, dim3(bs), 0, s, A);
     HIPCK(hipGetLastError());
     if (ctx->stage_timing) HIPCK(hipEventRecord(ev[4], s));
     return 0;

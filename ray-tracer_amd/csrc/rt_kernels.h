@@ -72,7 +72,23 @@ struct LevelCounters {
     unsigned long long walk_iters[2], walk_visits[2], walk_t0[2], walk_t1[2], walk_tsum[2], pad7[6];   // RT_WALK_STATS builds only: wave iterations, lane node visits, first start / last end / summed lifetime of the waves (100 MHz ticks)
 };
 
-constexpr int BLOCK = 1024;   // lanes per workgroup of the one-lane-per-ray kernels
+// Lanes per workgroup of the one-lane-per-ray kernels: the largest size; the host picks the size of a launch
+// (shade_block) and the kernels read it from blockDim. Every workgroup takes its queue slots with one atomic per counter
+// (same-address atomics are served one at a time), which speaks for large workgroups; but all waves of a workgroup meet
+// at two barriers, and with 1024 lanes a CU holds a single workgroup of k_gen_prims or k_shade_a at their register
+// counts. Measured: 512 lanes (two or three workgroups side by side) best for levels of millions of rays, 256 for the
+// short levels of a small shard, where whole workgroups are also too coarse a unit to spread over 256 CUs.
+#ifndef RT_BLOCK
+#define RT_BLOCK 512
+#endif
+constexpr int BLOCK = RT_BLOCK;
+#ifndef RT_SMALL_BLOCK
+#define RT_SMALL_BLOCK 256
+#endif
+#ifndef RT_SMALL_LEVEL
+#define RT_SMALL_LEVEL (2u << 20)
+#endif
+inline uint32_t shade_block(uint32_t level_capacity) { return level_capacity < RT_SMALL_LEVEL ? (uint32_t)RT_SMALL_BLOCK : (uint32_t)BLOCK; }
 
 struct LevelArgs {
     SceneDev S;             // by value: lands in the kernel-argument segment, read through scalar loads
@@ -175,12 +191,13 @@ __device__ __forceinline__ bool enters_box(const SceneDev &S, V3 ro, V3 rd, floa
 }
 
 // ---- stage 1 -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
+// six waves per SIMD (80 registers, no spills): three workgroups of a CU side by side
+__global__ __launch_bounds__(BLOCK, 6) void k_gen_prims(LevelArgs A) {
     __shared__ uint32_t s_wave[BLOCK / WAVE + 1];
     const SceneDev &S = A.S;
     const uint32_t n_rays = level_rays(A.n_src, A.n_rays);
-    if (blockIdx.x * BLOCK >= n_rays) return;   // the grid covers the capacity of the level
-    const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= n_rays) return;   // the grid covers the capacity of the level
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = tid < n_rays;
     V3 ro, rd;
     if (A.level == 0) {
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(BLOCK) void k_gen_prims(LevelArgs A) {
         // analytic primitives in scene order, strict `t < tMin` (js/8-kd_tree.js:1202-1214)
         for (int i = 0; i < S.n_prims; i++) {
             PHit h;
-            if (hit_prim(S, S.prims[i], ro, rd, h)) {
+            if (!surely_misses(S.prims[i], ro, rd) && hit_prim(S, S.prims[i], ro, rd, h)) {
                 last = (uint32_t)i;
                 if (h.t < tMin) { tMin = h.t; best = (uint32_t)i; }
             }
@@ -712,8 +729,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
     __shared__ uint32_t s_base[2];                                  // first slot of the workgroup in the child / shadow queue
     const SceneDev &S = A.S;
     const uint32_t n_rays = level_rays(A.n_src, A.n_rays);
-    if (blockIdx.x * BLOCK >= n_rays) return;
-    const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= n_rays) return;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = tid < n_rays;
     const uint32_t i = in_range ? tid : 0;
     const uint32_t hp = A.cur.hp[i];
@@ -761,7 +778,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
             bool occluded = false;
             for (int p = 0; p < S.n_prims && !occluded; p++) {
                 PHit h;
-                occluded = hit_prim(S, S.prims[p], so, sd, h);
+                occluded = !surely_misses(S.prims[p], so, sd) && hit_prim(S, S.prims[p], so, sd, h);
             }
             if (!occluded && S.render_triangles) {
                 if (S.use_kd) {
@@ -812,7 +829,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
     // only), 3 + l shadow ray towards light l that must walk the tree. The refracted rays of the workgroup take one run
     // of slots, the reflected ones the next, then (in the shadow queue) one run per light: neighbours in a queue are
     // rays of one kind from neighbouring pixels, which walk the same part of the tree.
-    constexpr uint32_t NW = BLOCK / WAVE;
+    const uint32_t NW = blockDim.x / WAVE;
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t n_kinds = 3u + (uint32_t)S.n_lights;
     const unsigned long long m_refr = __ballot(want_refr), m_refl = __ballot(want_refl), m_hit = __ballot(hit);
@@ -883,8 +900,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade_a(LevelArgs A) {
 __global__ __launch_bounds__(BLOCK) void k_shade_b(LevelArgs A) {
     const SceneDev &S = A.S;
     const uint32_t n_rays = level_rays(A.n_src, A.n_rays);
-    if (blockIdx.x * BLOCK >= n_rays) return;
-    const uint32_t tid = blockIdx.x * BLOCK + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= n_rays) return;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = tid < n_rays;
     const uint32_t i = in_range ? tid : 0;
     const uint32_t hp = A.cur.hp[i];
