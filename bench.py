@@ -46,7 +46,7 @@ TEAPOT = (os.path.join(ROOT, "assets", "models", "teapot.obj"), 60.0, (50.0, 75.
 
 
 def build_workload(model="bun_zipper.ply", teapot=True, time=0.0):
-    """BASELINE config 3: the default 8-kd_tree.js scene, full bunny + teapot.obj as a second mesh (indices rebased), the
+    """benchmark configuration 3: the default 8-kd_tree.js scene, full bunny + teapot.obj as a second mesh (indices rebased), the
     mesh material reflective and transmissive. tests/test_gpu_parity.py renders exactly this scene against the oracle."""
     sc = scene.default_scene(os.path.join(ROOT, "assets", "models", model), mesh_material=MESH_MATERIAL,
                              extra_mesh=TEAPOT if teapot else None)
@@ -267,7 +267,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic scene: the reference's generateScene() objects + Stanford bunny" + (" + teapot" if args.teapot else ""),
         "config": {
-            "workload": "BASELINE config 3: %s (%d faces)%s, default 8-kd_tree.js scene, reflective+transmissive mesh %s, %dx%d, depth %d, 2 lights, k-d tree, %s sharded over %d GPU(s)"
+            "workload": "benchmark configuration 3: %s (%d faces)%s, default 8-kd_tree.js scene, reflective+transmissive mesh %s, %dx%d, depth %d, 2 lights, k-d tree, %s sharded over %d GPU(s)"
                         % (args.model, len(flat.faces), " + teapot.obj" if args.teapot else "", str(MESH_MATERIAL), args.width, args.height, args.depth, "frames" if by_frames else "tiles", world),
             "rays_per_frame": rays, "shadow_rays_per_frame": shadow, "rays_per_level": per_level[:args.depth],
             "step": "rt_trace + luminance reduction" + (" + RCCL all-reduce + tile gather + assemble + present" if (world > 1 and not by_frames) else " + present"),

@@ -9,17 +9,17 @@ node $H --script $K8 --model models/bun_zipper_res4.ply --out $G/k8_res4_640x480
 node $H --script $K8 --model models/bun_zipper_res3.ply --out $G/k8_res3_640x480 --full-arrays
 node $H --script $K8 --model models/bun_zipper_res2.ply --out $G/k8_res2_640x480
 node $H --script $K8 --model models/bun_zipper.ply      --out $G/k8_full_640x480
-# BASELINE config 2: res4, depth 1, 1920x1080, light animated to t = 7.5 s
+# benchmark configuration 2: res4, depth 1, 1920x1080, light animated to t = 7.5 s
 node $H --script $K8 --model models/bun_zipper_res4.ply --width 1920 --height 1080 --time 7.5 --out $G/c2_res4_1920x1080
-# BASELINE config 3 host side: full bunny, depth 5, 3840x2160 (camera rays + uniforms; the k-d arrays equal k8_full)
+# benchmark configuration 3 host side: full bunny, depth 5, 3840x2160 (camera rays + uniforms; the k-d arrays equal k8_full)
 node $H --script $K8 --model models/bun_zipper_res4.ply --width 3840 --height 2160 --depth 5 --out $G/c3_rays_3840x2160
 # project.js / 7-tone_reproduction.js: depth 4, 2x2 supersampling, triangles off; tone stage on synthetic frames
 node $H --script project.js --out $G/project_640x480
 node $H --script 7-tone_reproduction.js --pixels zero --out $G/tone7_zero_640x480
 node $H --script 7-tone_reproduction.js --pixels const:10,200,30 --set TONE_REPRODUCTION_METHOD=1 --out $G/tone7_const_640x480
-# BASELINE config 1: checkpoint 6
+# benchmark configuration 1: checkpoint 6
 node $H --script 6-transmission.js --ticks 2 --out $G/c1_ch6_640x480
-# BASELINE config 3 as benchmarked: full bunny + teapot.obj (the reference's own loadOBJ and Mesh class; the harness
+# benchmark configuration 3 as benchmarked: full bunny + teapot.obj (the reference's own loadOBJ and Mesh class; the harness
 # rebases the second mesh's indices), reflective + transmissive mesh material, depth 5, 3840x2160
 node $H --script $K8 --model models/bun_zipper.ply --width 3840 --height 2160 --depth 5 \
      --mesh-material 0.7,0.6,0.7,16,0.3,0.5,0.9 --extra-obj models/teapot.obj --extra-scale 60 --extra-translate 50,75,10 \

@@ -1,5 +1,5 @@
 'use strict';
-// Animated frames from JavaScript (the job of BASELINE config 5): light 0 on the reference's orbit, the mesh dragged
+// Animated frames from JavaScript (the job of benchmark configuration 5): light 0 on the reference's orbit, the mesh dragged
 // with Mesh.translate (what the reference's mouse drag calls, js/8-kd_tree.js:2055-2064), the k-d tree rebuilt on the
 // GPU for every frame, and two RayTracer objects alternating frames so that JavaScript prepares frame k+1 (moves the
 // mesh, packs the arrays) while the GPU traces frame k. Prints a JSON summary.

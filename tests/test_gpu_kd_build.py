@@ -120,7 +120,7 @@ def test_frames_do_not_depend_on_where_the_tree_was_built():
 
 
 def test_animated_frames_with_rebuild_match_the_oracle():
-    """BASELINE config 5 in small: light 0 on its orbit, the mesh dragged, the tree rebuilt on the device for every
+    """benchmark configuration 5 in small: light 0 on its orbit, the mesh dragged, the tree rebuilt on the device for every
     frame, three frames in flight on alternating contexts. Every frame must equal the oracle's render of that
     frame's scene (the oracle builds its own tree from the moved vertices)."""
     import copy

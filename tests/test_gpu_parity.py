@@ -47,7 +47,7 @@ def check_against_oracle(flat, rect=None, threads=16):
 
 
 def test_config1_checkpoint6_scene_depth5():
-    """BASELINE config 1: checkpoint-6 scene (analytic primitives, one set light of two, INFINITY 100000.1)."""
+    """benchmark configuration 1: checkpoint-6 scene (analytic primitives, one set light of two, INFINITY 100000.1)."""
     flat = make_flat(None, 640, 480, depth=5, time=None, second_light=False, infinity=100000.1)
     check_against_oracle(flat)
 
@@ -63,7 +63,7 @@ def test_default_scene_res4_depth5_reflective_mesh():
 
 
 def test_config2_res4_1920x1080():
-    """BASELINE config 2: res4 bunny, primary rays + Phong, 1920x1080, light at t = 7.5 s."""
+    """benchmark configuration 2: res4 bunny, primary rays + Phong, 1920x1080, light at t = 7.5 s."""
     flat = make_flat("bun_zipper_res4.ply", 1920, 1080, depth=1, time=7.5)
     check_against_oracle(flat)
 
@@ -319,7 +319,7 @@ def test_config3_as_benchmarked_bunny_and_teapot_whole_4k_frame():
 
 
 def test_full_size_config3_properties_and_sampled_parity():
-    """BASELINE config 3 without the second mesh (69k-triangle bunny, depth 5, 3840x2160): parity with the oracle on
+    """benchmark configuration 3 without the second mesh (69k-triangle bunny, depth 5, 3840x2160): parity with the oracle on
     four 96x64 windows (sky+floor, sphere, bunny) and on a lattice of every third pixel in x and y over the whole frame,
     and frame-level properties: idempotence (two traces give the same bytes), ray accounting, background pixels exact."""
     flat = make_flat("bun_zipper.ply", 3840, 2160, depth=5, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))

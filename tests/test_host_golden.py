@@ -124,7 +124,7 @@ TWO_MESHES = [("bun_zipper_res4.ply", "k8_res4_teapot_640x480", 640, 480), ("bun
 
 @pytest.mark.parametrize("ply,gold,w,h", TWO_MESHES)
 def test_two_meshes_obj_ingest_rebase_and_trees_match_reference(ply, gold, w, h):
-    """BASELINE config 3 as benchmarked: bunny + teapot.obj. The fixture comes from the reference's own loadOBJ
+    """benchmark configuration 3 as benchmarked: bunny + teapot.obj. The fixture comes from the reference's own loadOBJ
     (js/8-kd_tree.js:2851-2887), Mesh class and builder; only the index rebase of the second mesh is the harness's.
     scene.load_obj + mesh_arrays(rebase=True), the oracle builder and the product builder reproduce every array."""
     m = manifest(gold)

@@ -34,7 +34,7 @@ def run_node(args, timeout=300):
 @pytest.mark.parametrize("golden", ["k8_res4_640x480", "k8_res3_640x480", "c2_res4_1920x1080", "k8_full_640x480",
                                     "k8_res4_teapot_640x480", "c3_bunny_teapot", "k8_res4_drag_640x480"])
 def test_js_scene_matches_reference_capture(golden):
-    """The two *teapot fixtures add a second mesh through loadOBJ with REBASE_MESH_INDICES (BASELINE config 3 as benchmarked).
+    """The two *teapot fixtures add a second mesh through loadOBJ with REBASE_MESH_INDICES (benchmark configuration 3 as benchmarked).
     The drag fixture was made by driving the reference's UI.mouseDown / mouseMove / mouseUp: class UI (js/ui.js) must
     grab the mesh at the same depth, follow the mouse through the same positions and leave the same transforms,
     vertices and tree."""

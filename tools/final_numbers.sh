@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: every number DESIGN.md quotes for this round, in one go (logs under gpurun_out/final_*).
+# GPU box: the headline bench, the shard rehearsal, configs 2 and 5 and the two-rank run in one go (logs under gpurun_out/final_*).
 set -o pipefail
 O=gpurun_out
 timeout -k 10 400 python3 -u bench.py > $O/final_bench.json 2> $O/final_bench.err || { echo bench failed; tail -5 $O/final_bench.err; exit 1; }
