@@ -267,7 +267,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic scene: the reference's generateScene() objects + Stanford bunny" + (" + teapot" if args.teapot else ""),
         "config": {
-            "workload": "benchmark configuration 3: %s (%d faces)%s, default 8-kd_tree.js scene, reflective+transmissive mesh %s, %dx%d, depth %d, 2 lights, k-d tree, %s sharded over %d GPU(s)"
+            "workload": "BASELINE.json config 3: %s (%d faces)%s, default 8-kd_tree.js scene, reflective+transmissive mesh %s, %dx%d, depth %d, 2 lights, k-d tree, %s sharded over %d GPU(s)"
                         % (args.model, len(flat.faces), " + teapot.obj" if args.teapot else "", str(MESH_MATERIAL), args.width, args.height, args.depth, "frames" if by_frames else "tiles", world),
             "rays_per_frame": rays, "shadow_rays_per_frame": shadow, "rays_per_level": per_level[:args.depth],
             "step": "rt_trace + luminance reduction" + (" + RCCL all-reduce + tile gather + assemble + present" if (world > 1 and not by_frames) else " + present"),

@@ -104,7 +104,7 @@ def main():
             "metric": "frames/s, animated project scene with a k-d rebuild per frame", "value": args.frames / dt, "unit": "frames/s",
             "n_gpus": world, "frames": args.frames, "ms_per_frame": dt / args.frames * 1e3, "mrays_per_s": rays / dt / 1e6,
             "mshadow_rays_per_s": shadow / dt / 1e6, "higher_is_better": True, "scaling": "strong", "dtype": "f32",
-            "config": {"workload": "benchmark configuration 5: default scene + %s, %dx%d, supersampling %d, depth %d, t = k/60, mesh dragged along a circle, %s"
+            "config": {"workload": "BASELINE.json config 5: default scene + %s, %dx%d, supersampling %d, depth %d, t = k/60, mesh dragged along a circle, %s"
                                    % (args.model, args.width, args.height, args.ss, args.depth,
                                       "no rebuild" if args.static else "tree rebuilt every frame by the %s builder" % args.kd_builder),
                        "frames_in_flight": len(rts), "sharding": "frame k on rank k mod N, no exchange"},
