@@ -133,7 +133,10 @@ void rt_default_config(rt_config *cfg);
  *      :1104-1126) and the shader regeneration of RayTracer.setScene (:2347-2431) --------
  * These calls and rt_set_mesh / rt_build_kdtree change host-side copies only; the device tables are refreshed by the
  * next rt_trace_begin, so they may be called while a frame is in flight. rt_build_kdtree_device replaces device arrays
- * the queued frame still reads and therefore fails between rt_trace_begin and rt_trace_end. */
+ * the queued frame still reads and therefore fails between rt_trace_begin and rt_trace_end.
+ * rt_prim.inv_model must be the inverse of rt_prim.model, as Primitive.translate / rotate / scale keep them
+ * (js/8-kd_tree.js:1245-1259): the intersection routines use inv_model like the shader, a bounding sphere that lets
+ * rays far from a sphere, cube or cylinder skip them is derived from model. */
 int rt_set_primitives(rt_ctx *ctx, const rt_prim *prims, int32_t n);
 int rt_set_materials(rt_ctx *ctx, const rt_material *mats, int32_t n);
 /* n_loop is the trip count of the light loop baked into the shader (`nextPointLightId`,
