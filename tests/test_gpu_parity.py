@@ -212,6 +212,34 @@ def _random_scene(seed, with_mesh):
     return sc, cam
 
 
+def test_axis_parallel_rays_and_an_unrotated_cube_off_to_the_side():
+    """The cube's slab test divides by the direction components: a ray with an exactly zero component (the centre column
+    and row of an odd-sized frame) sees NaN bounds on that axis, which min / max drop - the cube is then unbounded along
+    it, and the centre column reports hits on a cube that stands 100 units to the side. The shader's arithmetic, kept by
+    the oracle; the kernels' bounding-sphere filter must not remove those hits."""
+    from ray_tracer_amd.three_f32 import Vector3 as V
+    sc = scene.Scene()
+    ids = sc.ids
+    sc.lights.append(scene.PointLight(0, V(50, 200, 100), V(1, 1, 1)))
+    ids.light = 1
+    sc.n_lights_declared = 1
+    m = scene.Phong(0, 0.3, 0.6, 0.4, 16, 0.3, 0.0, 1.0, V(0.8, 0.2, 0.2), V(1, 1, 1))
+    ids.phong = 1
+    sc.materials.append(m)
+    for k, (x, y) in enumerate(((100, 0), (0, 90), (-120, -60))):
+        cube = scene.Cube(k)
+        cube.scale(V(40, 40, 40))
+        cube.translate(V(x, y, -300))
+        cube.setMaterial(m)
+        sc.objects.append(cube)
+    ids.object = 3
+    flat = abi.FlatScene(sc, abi.default_config(121, 81, depth=3), scene.camera_rays(121, 81))
+    rt, o, (_, _, got_id), cn = check_against_oracle(flat)
+    assert (got_id[:, 60] == 0).any()      # the centre column "hits" cube 0 although it stands to the right of it
+    assert (got_id[40, :] == 1).any()      # and the centre row the cube above it
+    rt.close()
+
+
 @pytest.mark.parametrize("seed", list(range(1, 25)))
 def test_random_scenes_match_the_oracle(seed):
     """Scenes nobody tuned: random transforms (rotated cylinders and cubes, stretched spheres), random materials of the
