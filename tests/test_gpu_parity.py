@@ -276,44 +276,70 @@ def test_empty_mesh_and_no_primitives():
     assert rt.stats().rays_total == 64 * 48 and rt.stats().shadow_rays == 0
 
 
-def test_sharded_render_assembles_to_the_full_frame():
-    """Two shard contexts on one GPU: tiles interleave, partial tone sums add up, the assembled frame
-    equals the unsharded one byte for byte."""
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_sharded_render_assembles_to_the_full_frame(n_shards):
+    """n shard contexts on one GPU (n = 3 does not divide the tile count; the frame is ragged on both edges): tiles
+    interleave, partial tone sums add up, the assembled render target equals the unsharded one byte for byte - and so
+    does the canvas when every shard tone-maps its own tiles (rt_present_shard) and the root only scatters them."""
     import ctypes as C
     flat = make_flat("bun_zipper_res4.ply", 203, 117, depth=3)
     full = render_hip(flat)
     want = full.readRGBA8()
     ws, wn = full.tonePartial()
-    parts, sums, cnt = [], 0.0, 0
+    full.toneFinish(ws, wn)
+    want_canvas = full.present()
     L = abi.lib()
     hip = C.CDLL("libamdhip64.so")
-    bufs = []
-    for r in range(2):
-        flat.cfg.shard_index, flat.cfg.shard_count = r, 2
+
+    def fetch(fn, rt):
+        p, nb = C.c_void_p(), C.c_size_t()
+        assert fn(rt.ctx, C.byref(p), C.byref(nb)) == 0
+        host = np.zeros(nb.value, np.uint8)
+        if nb.value:
+            assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), p, C.c_size_t(nb.value), 2) == 0
+        return host
+
+    def upload(bufs):
+        stride = -(-max(len(b) for b in bufs) // 256) * 256
+        gathered = np.zeros(stride * len(bufs), np.uint8)
+        for r, b in enumerate(bufs):
+            gathered[r * stride:r * stride + len(b)] = b
+        dptr = C.c_void_p()
+        assert hip.hipMalloc(C.byref(dptr), C.c_size_t(len(gathered))) == 0
+        assert hip.hipMemcpy(dptr, C.c_void_p(gathered.ctypes.data), C.c_size_t(len(gathered)), 1) == 0
+        return dptr, stride
+
+    parts, sums, cnt, bufs = [], 0.0, 0, []
+    for r in range(n_shards):
+        flat.cfg.shard_index, flat.cfg.shard_count = r, n_shards
         rt = render_hip(flat)
         s, n = rt.tonePartial()
         sums += s
         cnt += n
-        p, nb = C.c_void_p(), C.c_size_t()
-        assert L.rt_device_shard_rgba8(rt.ctx, C.byref(p), C.byref(nb)) == 0
-        host = np.zeros(nb.value, np.uint8)
-        assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), p, C.c_size_t(nb.value), 2) == 0
-        bufs.append(host)
+        bufs.append(fetch(L.rt_device_shard_rgba8, rt))
         parts.append(rt)
     flat.cfg.shard_index, flat.cfg.shard_count = 0, 1
     assert cnt == wn == 203 * 117
     assert abs(sums - ws) <= 1e-12 * abs(ws)
-    stride = max(len(b) for b in bufs)
-    gathered = np.zeros(stride * 2, np.uint8)
-    for r, b in enumerate(bufs):
-        gathered[r * stride:r * stride + len(b)] = b
     root = abi.RayTracerHIP(flat.cfg)
-    dptr = C.c_void_p()
-    assert hip.hipMalloc(C.byref(dptr), C.c_size_t(len(gathered))) == 0
-    assert hip.hipMemcpy(dptr, C.c_void_p(gathered.ctypes.data), C.c_size_t(len(gathered)), 1) == 0
-    assert L.rt_assemble_shards(root.ctx, dptr, C.c_size_t(stride), 2) == 0
+    dptr, stride = upload(bufs)
+    assert L.rt_assemble_shards(root.ctx, dptr, C.c_size_t(stride), n_shards) == 0
     assert np.array_equal(root.readRGBA8(), want)
     hip.hipFree(dptr)
+    # the canvas by shards: every shard finishes the tone values with the SAME global sums, presents its own tiles
+    canv = []
+    for rt in parts:
+        rt.toneFinish(ws, wn)
+        rt.presentShard()
+        canv.append(fetch(L.rt_device_shard_canvas, rt))
+    dptr, stride = upload(canv)
+    assert L.rt_assemble_shards_canvas(root.ctx, dptr, C.c_size_t(stride), n_shards) == 0
+    assert np.array_equal(device_canvas(root), want_canvas)
+    hip.hipFree(dptr)
+    # a stride that no shard of this frame can have is refused
+    assert L.rt_assemble_shards(root.ctx, dptr, C.c_size_t(stride * 64), n_shards) != 0
+    for rt in parts + [root, full]:
+        rt.close()
 
 
 def test_config3_as_benchmarked_bunny_and_teapot_whole_4k_frame():
