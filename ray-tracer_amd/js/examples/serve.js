@@ -86,8 +86,14 @@ v.addEventListener('contextmenu', function (e) { e.preventDefault(); });
             next();
         } else if (req.method === 'POST' && req.url === '/event') {
             const parts = [];
-            req.on('data', (d) => parts.push(d));
+            let size = 0;
+            req.on('data', (d) => {
+                size += d.length;
+                if (size > 4096) { res.writeHead(413); res.end(); req.destroy(); return; }   // an event is a few dozen bytes
+                parts.push(d);
+            });
             req.on('end', () => {
+                if (size > 4096) return;
                 try {
                     const ev = JSON.parse(Buffer.concat(parts).toString('utf8'));
                     if (!/^(mousedown|mousemove|mouseup|wheel)$/.test(ev.type)) throw new Error('unknown event type');
