@@ -7,46 +7,91 @@
 // (js/loaders/OBJLoader.js:653-655).
 const fs = require('fs');
 
-function parsePLY(text) {
-    const cut = text.search(/end_header\s/);
-    if (cut < 0) throw new Error('loadPLY: no end_header');
-    const head = text.slice(0, cut).split('\n');
-    const bodyStart = text.indexOf('\n', cut) + 1;
+const PLY_TYPES = {
+    int8: ['getInt8', 1], char: ['getInt8', 1], uint8: ['getUint8', 1], uchar: ['getUint8', 1],
+    int16: ['getInt16', 2], short: ['getInt16', 2], uint16: ['getUint16', 2], ushort: ['getUint16', 2],
+    int32: ['getInt32', 4], int: ['getInt32', 4], uint32: ['getUint32', 4], uint: ['getUint32', 4],
+    float32: ['getFloat32', 4], float: ['getFloat32', 4], float64: ['getFloat64', 8], double: ['getFloat64', 8],
+};
+
+// data: a Buffer with the whole file (ASCII, binary_little_endian or binary_big_endian; js/loaders/PLYLoader.js:252-486)
+function parsePLY(data) {
+    if (typeof data === 'string') data = Buffer.from(data, 'latin1');
+    const probe = data.toString('latin1', 0, Math.min(data.length, 1 << 16));
+    const hm = /ply([\s\S]*?)end_header\s/.exec(probe);
+    if (!hm) throw new Error('loadPLY: no end_header');
+    const bodyStart = hm.index + hm[0].length;
+    let format = 'ascii';
     const elements = [];
-    for (const line of head) {
+    for (const line of hm[1].split('\n')) {
         const tok = line.trim().split(/\s+/);
-        if (tok[0] === 'format' && tok[1] !== 'ascii') throw new Error('loadPLY: only ASCII PLY is supported');
-        if (tok[0] === 'element') elements.push({ name: tok[1], count: parseInt(tok[2], 10), props: [] });
-        else if (tok[0] === 'property') elements[elements.length - 1].props.push(tok[tok.length - 1]);
+        if (tok[0] === 'format') format = tok[1];
+        else if (tok[0] === 'element') elements.push({ name: tok[1], count: parseInt(tok[2], 10), props: [] });
+        else if (tok[0] === 'property') {
+            elements[elements.length - 1].props.push(tok[1] === 'list'
+                ? { list: true, countType: tok[2], itemType: tok[3], name: tok[4] } : { list: false, type: tok[1], name: tok[2] });
+        }
     }
     const positions = [], indices = [];
-    let pos = bodyStart;
-    const nextLine = () => {
-        for (;;) {
-            let end = text.indexOf('\n', pos);
-            if (end < 0) end = text.length;
-            const line = text.slice(pos, end).trim();
-            pos = end + 1;
-            if (line !== '' || pos > text.length) return line;
-        }
+    const addFace = (ix) => {
+        if (ix.length === 3) indices.push(ix[0], ix[1], ix[2]);
+        else if (ix.length === 4) indices.push(ix[0], ix[1], ix[3], ix[1], ix[2], ix[3]);
     };
-    for (const el of elements) {
-        if (el.name === 'vertex') {
-            const ix = el.props.indexOf('x'), iy = el.props.indexOf('y'), iz = el.props.indexOf('z');
-            for (let i = 0; i < el.count; i++) {
-                const t = nextLine().split(/\s+/);
-                positions.push(parseFloat(t[ix]), parseFloat(t[iy]), parseFloat(t[iz]));
+    if (format === 'ascii') {
+        const text = data.toString('latin1', bodyStart);
+        let pos = 0;
+        const nextLine = () => {
+            for (;;) {
+                let end = text.indexOf('\n', pos);
+                if (end < 0) end = text.length;
+                const line = text.slice(pos, end).trim();
+                pos = end + 1;
+                if (line !== '' || pos > text.length) return line;
             }
-        } else if (el.name === 'face') {
-            for (let i = 0; i < el.count; i++) {
-                const t = nextLine().split(/\s+/).map((s) => parseInt(s, 10));
-                if (t[0] === 3) indices.push(t[1], t[2], t[3]);
-                else if (t[0] === 4) indices.push(t[1], t[2], t[4], t[2], t[3], t[4]);
+        };
+        for (const el of elements) {
+            const names = el.props.map((p) => p.name);
+            if (el.name === 'vertex') {
+                const ix = names.indexOf('x'), iy = names.indexOf('y'), iz = names.indexOf('z');
+                for (let i = 0; i < el.count; i++) {
+                    const t = nextLine().split(/\s+/);
+                    positions.push(parseFloat(t[ix]), parseFloat(t[iy]), parseFloat(t[iz]));
+                }
+            } else if (el.name === 'face') {
+                for (let i = 0; i < el.count; i++) {
+                    const t = nextLine().split(/\s+/).map((s) => parseInt(s, 10));
+                    addFace(t.slice(1, 1 + t[0]));
+                }
+            } else {
+                for (let i = 0; i < el.count; i++) nextLine();
             }
-        } else {
-            for (let i = 0; i < el.count; i++) nextLine();
         }
-    }
+    } else if (format === 'binary_little_endian' || format === 'binary_big_endian') {
+        const little = format === 'binary_little_endian';
+        const view = new DataView(data.buffer, data.byteOffset + bodyStart, data.length - bodyStart);
+        let at = 0;
+        const read = (type) => {
+            const t = PLY_TYPES[type];
+            if (!t) throw new Error('loadPLY: unknown property type ' + type);
+            const v = view[t[0]](at, little);
+            at += t[1];
+            return v;
+        };
+        for (const el of elements) {
+            for (let i = 0; i < el.count; i++) {
+                const rec = {};
+                for (const p of el.props) {
+                    if (p.list) {
+                        const n = read(p.countType), list = [];
+                        for (let k = 0; k < n; k++) list.push(read(p.itemType));
+                        rec[p.name] = list;
+                    } else rec[p.name] = read(p.type);
+                }
+                if (el.name === 'vertex') positions.push(rec.x, rec.y, rec.z);
+                else if (el.name === 'face') addFace(rec.vertex_indices || rec.vertex_index);
+            }
+        }
+    } else throw new Error('loadPLY: format ' + format);
     return { positions: new Float32Array(positions), indices };
 }
 
@@ -80,9 +125,9 @@ function makeLoaders(G, THREE, Triangle) {
     }
     function loadPLY(filename) {
         return new Promise((resolve, reject) => {
-            fs.readFile(resolvePath(filename), 'utf8', (err, text) => {
+            fs.readFile(resolvePath(filename), (err, data) => {
                 if (err) return reject(err);
-                try { resolve(toMesh(parsePLY(text))); } catch (e) { reject(e); }
+                try { resolve(toMesh(parsePLY(data))); } catch (e) { reject(e); }
             });
         });
     }

@@ -152,47 +152,82 @@ class Mesh(Primitive):
 
 # ---- loaders -------------------------------------------------------------------------------
 
+_PLY_TYPES = {"int8": "b", "char": "b", "uint8": "B", "uchar": "B", "int16": "h", "short": "h", "uint16": "H", "ushort": "H",
+              "int32": "i", "int": "i", "uint32": "I", "uint": "I", "float32": "f", "float": "f", "float64": "d", "double": "d"}
+
+
 def load_ply(path):
-    """ASCII PLY -> (verts f64 holding f32 values, faces). Mirrors THREE.PLYLoader.parseASCII
-    (js/loaders/PLYLoader.js:252-388: positions pass through a Float32BufferAttribute; quads split
-    0-1-3 / 1-2-3) followed by Geometry.fromBufferGeometry (vertex and face order kept)."""
-    with open(path, "r") as f:
-        text = f.read()
-    head, body = re.split(r"end_header\s", text, maxsplit=1)
+    """PLY (ASCII, binary_little_endian or binary_big_endian) -> (verts f64 holding f32 values, faces). Mirrors
+    THREE.PLYLoader (js/loaders/PLYLoader.js:252-388 parseASCII, :392-486 parseBinary: positions pass through a
+    Float32BufferAttribute; quads split 0-1-3 / 1-2-3; the face list is `vertex_indices` or `vertex_index`) followed by
+    Geometry.fromBufferGeometry (vertex and face order kept)."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    m = re.search(rb"ply([\s\S]*?)end_header\s", data)
+    if not m:
+        raise ValueError("not a PLY file: no header")
+    fmt = "ascii"
     elements = []
-    for line in head.split("\n"):
+    for line in m.group(1).decode("latin-1").split("\n"):
         tok = line.split()
         if not tok:
             continue
-        if tok[0] == "format" and tok[1] != "ascii":
-            raise ValueError("only ASCII PLY is supported")
-        if tok[0] == "element":
+        if tok[0] == "format":
+            fmt = tok[1]
+        elif tok[0] == "element":
             elements.append([tok[1], int(tok[2]), []])
         elif tok[0] == "property":
             elements[-1][2].append(tok[1:])
-    lines = [ln for ln in (l.strip() for l in body.split("\n")) if ln]
-    pos = 0
     verts, faces = [], []
-    for name, count, props in elements:
-        rows = lines[pos:pos + count]
-        pos += count
-        if name == "vertex":
-            names = [p[-1] for p in props]
-            ix, iy, iz = names.index("x"), names.index("y"), names.index("z")
-            for r in rows:
-                t = r.split()
-                verts.append((float(t[ix]), float(t[iy]), float(t[iz])))
-        elif name == "face":
-            for r in rows:
-                t = [int(v) for v in r.split()]
-                n, idx = t[0], t[1:]
-                if n == 3:
-                    faces.append((idx[0], idx[1], idx[2]))
-                elif n == 4:
-                    faces.append((idx[0], idx[1], idx[3]))
-                    faces.append((idx[1], idx[2], idx[3]))
-    v = np.array(verts, dtype=np.float64).astype(np.float32).astype(np.float64)
-    return v, np.array(faces, dtype=np.uint32)
+
+    def add_face(idx):
+        if len(idx) == 3:
+            faces.append((idx[0], idx[1], idx[2]))
+        elif len(idx) == 4:
+            faces.append((idx[0], idx[1], idx[3]))
+            faces.append((idx[1], idx[2], idx[3]))
+
+    if fmt == "ascii":
+        lines = [ln for ln in (l.strip() for l in data[m.end():].decode("latin-1").split("\n")) if ln]
+        pos = 0
+        for name, count, props in elements:
+            rows = lines[pos:pos + count]
+            pos += count
+            if name == "vertex":
+                names = [p[-1] for p in props]
+                ix, iy, iz = names.index("x"), names.index("y"), names.index("z")
+                for r in rows:
+                    t = r.split()
+                    verts.append((float(t[ix]), float(t[iy]), float(t[iz])))
+            elif name == "face":
+                for r in rows:
+                    t = [int(v) for v in r.split()]
+                    add_face(t[1:1 + t[0]])
+    elif fmt in ("binary_little_endian", "binary_big_endian"):
+        e = "<" if fmt == "binary_little_endian" else ">"
+        at = m.end()
+        for name, count, props in elements:
+            for _ in range(count):
+                rec = {}
+                for p in props:
+                    if p[0] == "list":
+                        n, = struct.unpack_from(e + _PLY_TYPES[p[1]], data, at)
+                        at += struct.calcsize(_PLY_TYPES[p[1]])
+                        item = e + str(n) + _PLY_TYPES[p[2]]
+                        rec[p[3]] = list(struct.unpack_from(item, data, at))
+                        at += struct.calcsize(item)
+                    else:
+                        rec[p[1]], = struct.unpack_from(e + _PLY_TYPES[p[0]], data, at)
+                        at += struct.calcsize(_PLY_TYPES[p[0]])
+                if name == "vertex":
+                    verts.append((float(rec["x"]), float(rec["y"]), float(rec["z"])))
+                elif name == "face":
+                    add_face(rec.get("vertex_indices") or rec.get("vertex_index"))
+    else:
+        raise ValueError("PLY format %r" % fmt)
+    v = np.array(verts, dtype=np.float64).reshape(-1, 3).astype(np.float32).astype(np.float64)
+    return v, np.array(faces, dtype=np.uint32).reshape(-1, 3)
 
 
 def load_obj(path):

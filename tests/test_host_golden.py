@@ -3,6 +3,7 @@ running the reference's own JavaScript under Node (oracle/gen_golden/ref_capture
 uniforms (matrices, camera rays, light animation), mesh ingest (f64 vertices, faces, face materials),
 the k-d tree arrays of the ORACLE builder and of the PRODUCT builder (host-only context), Lbar / sf."""
 import ctypes as C
+import json
 import os
 import re
 
@@ -163,6 +164,74 @@ def test_two_meshes_obj_ingest_rebase_and_trees_match_reference(ply, gold, w, h)
         assert np.array_equal(getattr(flat, n), f32(U[n])), n
     assert m["glsl_counts"]["ray_tree_size"] == 2 ** int(m["constant_edits"]["MAX_RECURSION_DEPTH"]) - 1
     assert m["glsl_counts"]["num_faces"] == len(f)
+
+
+def _ply_variants(tmp_path):
+    """The smallest bunny plus one quad, written as ASCII, binary little-endian (float coordinates, uchar / int face
+    lists) and binary big-endian (double coordinates, ushort counts / uint indices, an extra element in front)."""
+    import struct
+    from ray_tracer_amd import scene
+    v, f = scene.load_ply(model("bun_zipper_res4.ply"))
+    extra = np.random.default_rng(3).uniform(0, 1, size=(len(v), 2))
+    quad = (0, 1, 2, 3)
+    head = lambda fmt, t, cnt, idx, pre="": ("ply\nformat %s 1.0\ncomment test file\n%selement vertex %d\nproperty %s x\nproperty %s y\n"
+                                             "property %s z\nproperty float confidence\nproperty float intensity\nelement face %d\n"
+                                             "property list %s %s vertex_indices\nend_header\n" % (fmt, pre, len(v), t, t, t, len(f) + 1, cnt, idx)).encode()
+    a = tmp_path / "a.ply"
+    with open(a, "wb") as fh:
+        fh.write(head("ascii", "float", "uchar", "int"))
+        for p, e in zip(v, extra):
+            fh.write(("%r %r %r %r %r\n" % (float(np.float32(p[0])), float(np.float32(p[1])), float(np.float32(p[2])), e[0], e[1])).encode())
+        for t in f:
+            fh.write(("3 %d %d %d\n" % tuple(t)).encode())
+        fh.write(("4 %d %d %d %d\n" % quad).encode())
+    le = tmp_path / "le.ply"
+    with open(le, "wb") as fh:
+        fh.write(head("binary_little_endian", "float", "uchar", "int"))
+        for p, e in zip(v, extra):
+            fh.write(struct.pack("<fffff", p[0], p[1], p[2], e[0], e[1]))
+        for t in f:
+            fh.write(struct.pack("<Biii", 3, *[int(x) for x in t]))
+        fh.write(struct.pack("<Biiii", 4, *quad))
+    be = tmp_path / "be.ply"
+    with open(be, "wb") as fh:
+        fh.write(head("binary_big_endian", "double", "ushort", "uint", pre="element marker 2\nproperty short tag\n"))
+        fh.write(struct.pack(">hh", 7, -7))
+        for p, e in zip(v, extra):
+            fh.write(struct.pack(">dddff", p[0], p[1], p[2], e[0], e[1]))
+        for t in f:
+            fh.write(struct.pack(">HIII", 3, *[int(x) for x in t]))
+        fh.write(struct.pack(">HIIII", 4, *quad))
+    want_f = np.concatenate([f, np.array([[0, 1, 3], [1, 2, 3]], np.uint32)])
+    return v, want_f, [str(a), str(le), str(be)]
+
+
+def test_binary_ply_little_and_big_endian(tmp_path):
+    """THREE.PLYLoader also reads binary PLY (js/loaders/PLYLoader.js:392-486). Both loaders (scene.load_ply and
+    js/loaders.js) must return, for a little-endian and a big-endian file, what they return for the ASCII file: the same
+    float32 positions, the same triangles, a quad split 0-1-3 / 1-2-3. Where the reference checkout is present its own
+    PLYLoader parses the three files too and must agree."""
+    import shutil
+    import subprocess
+    from ray_tracer_amd import scene
+    v, want_f, files = _ply_variants(tmp_path)
+    for path in files:
+        gv, gf = scene.load_ply(path)
+        assert np.array_equal(gv, v) and np.array_equal(gf, want_f), path
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node is missing")
+    ref = "/root/reference" if os.path.exists("/root/reference/js/loaders/PLYLoader.js") else None
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ray-tracer_amd", "js", "test", "ply_check.js")
+    p = subprocess.run([node, script, ",".join(files)] + ([ref] if ref else []), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    want_pos = sha(v.astype(np.float32))
+    for rec in out:
+        assert rec["n_verts"] == len(v) and rec["n_faces"] == len(want_f)
+        assert rec["positions_sha256"] == want_pos and rec["indices_sha256"] == sha(want_f), rec["file"]
+        if ref:
+            assert rec["reference_equal"] is True, rec["file"]
 
 
 def test_kd_edge_cases():
