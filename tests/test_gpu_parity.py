@@ -212,6 +212,23 @@ def _random_scene(seed, with_mesh):
     return sc, cam
 
 
+def test_repeated_frames_are_bit_identical():
+    """Which wave walks which ray, who steals what and the order of the atomics change from run to run; the frame must
+    not: twelve traces of one scene (full bunny, depth 5, 960x540) in one context give the same float colours, bytes
+    and hit ids every time."""
+    flat = make_flat("bun_zipper.ply", 960, 540, depth=5, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    rt = abi.RayTracerHIP(flat.cfg)
+    rt.setScene(flat, kd_on_device=True)
+    first = None
+    for k in range(12):
+        rt.trace()
+        got = (sha(rt.readFloat()), sha(rt.readRGBA8()), sha(rt.readHitIds()), rt.stats().rays_total)
+        if first is None:
+            first = got
+        assert got == first, k
+    rt.close()
+
+
 def test_axis_parallel_rays_and_an_unrotated_cube_off_to_the_side():
     """The cube's slab test divides by the direction components: a ray with an exactly zero component (the centre column
     and row of an odd-sized frame) sees NaN bounds on that axis, which min / max drop - the cube is then unbounded along
