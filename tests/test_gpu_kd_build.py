@@ -162,3 +162,35 @@ def test_animated_frames_with_rebuild_match_the_oracle():
         assert np.array_equal(rt.readRGBA8(), want_8), k
         assert np.array_equal(rt.readFloat(), want_f, equal_nan=True), k
         assert rt.stats().rays_total == cn.rays
+
+
+def test_one_animated_frame_at_full_size_matches_the_oracle():
+    """The animated benchmark at its real size: full bunny, 3840x2160, depth 4, frame 37 of the run (light 0 on its
+    orbit, the mesh moved along its circle), the tree rebuilt on the device - after a first build at rest, so that this
+    is a rebuild over predicted sizes. The whole frame must equal the oracle's render of the moved scene."""
+    import copy
+    import math
+    flat = make_flat("bun_zipper.ply", 3840, 2160, depth=4)
+    base = np.ascontiguousarray(flat.verts, np.float64)
+    rt = abi.RayTracerHIP(flat.cfg)
+    rt.setScene(flat, kd_on_device=True)
+    rt.trace()
+    k = 37
+    t = k / 60.0
+    x = 500.0 * math.cos(2.0 * math.pi * (t % 60.0) / 60.0)
+    lights = [((x, 300.0, x - 280.0), flat.lights[0][1])] + list(flat.lights[1:])
+    a = 2.0 * math.pi * k / 240.0
+    verts = base + np.array([12.0 * math.sin(a), 0.0, 12.0 * (math.cos(a) - 1.0)])
+    rt.setLights(lights, flat.n_lights_loop)
+    rt.setMesh(verts, flat.faces, flat.face_mat)
+    rt.buildKdTree(on_device=True)
+    rt.trace()
+    f = copy.copy(flat)
+    f.lights, f.verts = lights, verts
+    want_f, want_8, want_id, cn = oracle.OracleRenderer(f).trace(threads=16)
+    assert np.array_equal(rt.readHitIds(), want_id)
+    assert np.array_equal(rt.readRGBA8(), want_8)
+    assert np.array_equal(rt.readFloat(), want_f, equal_nan=True)
+    st = rt.stats()
+    assert st.rays_total == cn.rays and st.shadow_rays == cn.shadow_rays
+    rt.close()
