@@ -154,7 +154,7 @@ def main():
                              device=local, parts=args.parts)
     flat = abi.FlatScene(sc, cfg, scene.camera_rays(args.width, args.height))
     pipelined = not args.sync_job and (world == 1 or by_frames or args.backend == "nccl")
-    in_flight = args.in_flight if args.in_flight > 0 else (3 if shard_count <= 1 else 6 if shard_count == 2 else 8 if shard_count <= 4 else 12)
+    in_flight = args.in_flight if args.in_flight > 0 else (3 if shard_count <= 1 else 6 if shard_count == 2 else 12)
     n_ctx = in_flight if pipelined else 1
     t0 = time.perf_counter()
     rts = []
