@@ -110,7 +110,7 @@ def main():
                          "(own tiles only), or the shard's trace followed by a present pass over the whole frame")
     ap.add_argument("--parts", type=int, default=0, help="concurrent slices per GPU (0 = library default)")
     ap.add_argument("--in-flight", type=int, default=0, help="frames in flight per GPU (contexts that alternate frames); 1 = finish every frame before the next; "
-                                                             "0 = 3 for a whole frame per GPU, 6 / 8 / 12 for a half / a quarter / an eighth of it (a small shard leaves the GPU room for more)")
+                                                             "0 = 3 for a whole frame per GPU, 6 / 12 / 12 for a half / a quarter / an eighth of it (a small shard leaves the GPU room for more)")
     ap.add_argument("--walk-waves", type=int, default=0, help="persistent walk waves per CU and context (0 = 24, 20 when tiles are exchanged between GPUs)")
     ap.add_argument("--sync-job", action="store_true", help="the host-synchronised frame job (every stage of the exchange waits on the host)")
     ap.add_argument("--kd-builder", default="host", choices=["host", "device"], help="where the k-d tree is built (same tree; the node blocks are laid out in a different order)")
