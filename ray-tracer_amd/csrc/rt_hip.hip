@@ -284,6 +284,7 @@ int device_build(rt_ctx *ctx) {
         return -1;
     }
     if (ctx->gpu_kd->tree.n_slots > (1u << LEAF_COUNT_SHIFT)) return fail(ctx, "rt_build_kdtree_device: k-d tree has too many leaf slots for the device layout (2^24)");
+    detach_shared_tree(ctx);   // an uploaded host-built tree is no longer this context's
     ctx->st.kd_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->st.kd_upload_ms = 0.0;
     return 0;
