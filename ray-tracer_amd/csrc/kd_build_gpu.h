@@ -72,8 +72,9 @@ private:
     uint32_t cap_level_nodes = 0;
     uint32_t *pool_face[2] = {nullptr, nullptr}, *pool_owner[2] = {nullptr, nullptr};
     uint32_t cap_pool = 0;
-    uint32_t *flags = nullptr, *scanned = nullptr;          // 2 * cap_pool + 1
-    uint32_t *child_flag = nullptr, *child_scan = nullptr;  // 2 * cap_level_nodes + 1
+    uint32_t *flags = nullptr;                               // cap_pool + 1: which children a face goes on into
+    uint2 *scanned = nullptr;                                // cap_pool + 1: faces in front that go on into child 0 / child 1
+    uint32_t *child_flag = nullptr;                          // 2 * cap_level_nodes + 1
     uint32_t *child_count = nullptr, *child_start = nullptr, *owner_map = nullptr;
     unsigned long long *code_count = nullptr, *code_scan = nullptr;   // 2^PATH_BITS + 1
     uint32_t *leaf_heap = nullptr, *leaf_count = nullptr, *leaf_pos = nullptr, *leaf_faces = nullptr;
@@ -86,6 +87,8 @@ private:
     uint32_t hist_pool[26] = {}, hist_active[26] = {}, hist_leaves = 0, hist_used = 0;
     int hist_levels = 0, hist_max_depth = 0;
     int64_t hist_faces = -1;
+    uint32_t *chain = nullptr;                               // states of the sums computed inside k_kd_test / k_kd_emit
+    size_t cap_chain = 0;
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     uint32_t cap_node_slots = 0, cap_slots = 0, cap_tris = 0, cap_leaf_table = 0;

@@ -7,14 +7,16 @@
 // the upper child first, js/8-kd_tree.js:1677,:1718); it is restored at the end from the leaves' positions in the tree.
 //
 // One level = all nodes of one depth that still split ("active"). Their face lists sit back to back in a pool.
-//   k_kd_test      one lane per (node, face): the two child boxes, two overlap tests, two flags
-//   scan           exclusive sum over the flags, laid out per node as [flags of child 0][flags of child 1]: a child's
-//                  list is contiguous in the next pool and keeps the parent's order
+//   k_kd_test      one lane per (node, child, face): the child's box, the overlap test, a flag - and the exclusive sum
+//                  over the flags, laid out per node as [flags of child 0][flags of child 1]: a child's list is
+//                  contiguous in the next pool and keeps the parent's order
 //   k_kd_scatter   faces to their places in the next pool
 //   k_kd_classify  one lane per child: size of its list -> splits again / leaf / empty leaf
-//   scan           rank of the children that split = their index among the next level's active nodes
-//   k_kd_emit      node records in the treelet layout, boxes of the next level, leaves to a list
+//   k_kd_emit      rank of the children that split = their index among the next level's active nodes; node records in
+//                  the treelet layout, boxes of the next level, leaves to a list
 // and at the end the leaves are numbered and their triangles laid out in leaf order (k_kd_leaf_*).
+// The two exclusive sums of a level are computed inside the kernels that produce their input (chained_rank below), so
+// a level is three dependent launches.
 #include "kd_build_gpu.h"
 
 #include <hipcub/hipcub.hpp>
@@ -29,10 +31,10 @@ namespace {
 constexpr uint32_t T_INTERNAL = 1u << 30, T_EMPTY = 2u << 30, T_LEAF = 3u << 30;
 constexpr uint32_t NONE = 0xffffffffu;
 constexpr uint32_t CODES = 1u << PATH_BITS;
-enum { C_LEAVES = 0, C_PAIRS = 1, C_EMPTY = 2, C_WORDS = 4 };
+enum { C_LEAVES = 0, C_PAIRS = 1, C_EMPTY = 2, C_STALL = 3, C_WORDS = 4 };
 // state of one level in device memory: what the level before it produced. The kernels of a level read their sizes
 // from here, so that the host can queue all levels without waiting for any of them (grids are sized by bounds).
-enum { ST_POOL = 0, ST_ACTIVE = 1, ST_BLOCK = 2, ST_USED = 3, ST_OVER = 4, ST_WORDS = 8 };
+enum { ST_POOL = 0, ST_ACTIVE = 1, ST_BLOCK = 2, ST_USED = 3, ST_OVER = 4, ST_LEAVES = 5, ST_PAIRS = 6, ST_EMPTY = 7, ST_WORDS = 8 };
 constexpr int MAX_BUILD_LEVELS = 26;
 
 struct Nodes {
@@ -62,11 +64,19 @@ inline unsigned long long host_order_key(double x) {
 __global__ __launch_bounds__(256) void k_kd_root_box(const double *verts, const uint32_t *faces, uint32_t n_faces,
                                                      unsigned long long *keys /* lo xyz, hi xyz */) {
     const uint32_t f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= n_faces) return;
     for (int k = 0; k < 3; k++) {
-        const unsigned long long c = order_key(verts[3 * (size_t)faces[3 * (size_t)f + k] + k]);
-        atomicMin(&keys[k], c);
-        atomicMax(&keys[3 + k], c);
+        // one atomic pair per wave: atomics on one address are served one after the other
+        unsigned long long lo = ~0ull, hi = 0ull;
+        if (f < n_faces) lo = hi = order_key(verts[3 * (size_t)faces[3 * (size_t)f + k] + k]);
+        for (int o = 32; o; o >>= 1) {
+            const unsigned long long a = (unsigned long long)__shfl_xor((long long)lo, o), b = (unsigned long long)__shfl_xor((long long)hi, o);
+            lo = a < lo ? a : lo;
+            hi = b > hi ? b : hi;
+        }
+        if ((threadIdx.x & 63u) == 0u && lo <= hi) {
+            atomicMin(&keys[k], lo);
+            atomicMax(&keys[3 + k], hi);
+        }
     }
 }
 
@@ -91,80 +101,178 @@ __global__ __launch_bounds__(256) void k_kd_iota(uint32_t *a, uint32_t n) {
     if (i < n) a[i] = i;
 }
 
+// ---- exclusive sums over K flags per lane across all workgroups of a launch, in a single pass ----
+// A launch of T workgroups owns K x (T + ceil(T / 256)) words that are zero when it starts. For each of the K flags,
+// own[i] becomes CHAIN_VALID | the number of flags set in workgroup i as soon as that is known (value and mark travel in
+// one word, so no fence is needed between them). Up to CHAIN_FLAT workgroups, every workgroup simply adds up the own
+// counts of ALL workgroups in front of it, each lane taking every 256th: T^2 / 2 loads in all, which is nothing for a few
+// thousand workgroups, and the only wait is "everybody in front has counted". Larger launches go in two steps:
+// group[g] becomes CHAIN_VALID | the number set in workgroups 256 g .. 256 g + 255, published by the last of them
+// before it looks at the groups in front, and a workgroup adds the own counts in front of it in its group (one per
+// lane) and the totals of the groups in front of that. Either way there is no chain of dependent hand-overs: a value
+// takes about as long from one workgroup to another as a small kernel takes in all.
+// A workgroup only ever waits for workgroups with a lower index: those are dispatched before it, so they are running or
+// done. A wait that lasts longer than any launch could (a fraction of a second) gives up and says so in *stall: the
+// build is then reported as failed, and no wave ever waits without end.
+constexpr uint32_t CHAIN_VALID = 0x80000000u;
+constexpr uint32_t CHAIN_POLL_LIMIT = 1u << 18;
+constexpr uint32_t CHAIN_FLAT = 2048;
+constexpr int CHAIN_SHARED_WORDS_PER_FLAG = 12;
+
+__device__ __forceinline__ uint32_t chain_wait(const uint32_t *word, uint32_t *stall) {
+    uint32_t v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t polls = 0; !(v & CHAIN_VALID); polls++) {
+        if (polls > CHAIN_POLL_LIMIT) { *stall = 1u; break; }
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return v & ~CHAIN_VALID;
+}
+// sums over the 256 lanes of the workgroup, K at a time; slots = 4 K words of shared memory that nothing else uses
+// meanwhile (they keep the sums of the four waves)
+template <int K>
+__device__ __forceinline__ void chain_block_sums(uint32_t (&x)[K], uint32_t *slots) {
+    for (int k = 0; k < K; k++) {
+        uint32_t v = x[k];
+        for (int o = 32; o; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+        if ((threadIdx.x & 63u) == 0u) slots[4 * k + (threadIdx.x >> 6)] = v;
+    }
+    __syncthreads();
+    for (int k = 0; k < K; k++) x[k] = slots[4 * k] + slots[4 * k + 1] + slots[4 * k + 2] + slots[4 * k + 3];
+}
+
+// every lane of the 256-lane workgroup calls it. rank[k] = number of set flags k in front of this lane's, over the whole
+// launch; upto[k] = the same including the whole workgroup. sh: K * CHAIN_SHARED_WORDS_PER_FLAG words.
+template <int K>
+__device__ __forceinline__ void chained_ranks(uint32_t *chain, const bool (&flag)[K], uint32_t *sh, uint32_t *stall,
+                                              uint32_t (&rank)[K], uint32_t (&upto)[K]) {
+    const uint32_t tile = blockIdx.x, tiles = gridDim.x, wave = threadIdx.x >> 6;
+    const uint32_t stride = tiles + ((tiles + 255u) >> 8);   // words per flag: own counts, then group totals
+    uint32_t own[K], part[K];
+    for (int k = 0; k < K; k++) own[k] = flag[k] ? 1u : 0u;
+    chain_block_sums<K>(own, sh);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < K; k++)
+            __hip_atomic_store(chain + k * stride + tile, CHAIN_VALID | own[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < K; k++) part[k] = 0u;
+    if (tiles <= CHAIN_FLAT) {
+        for (uint32_t i = threadIdx.x; i < tile; i += 256u)
+            for (int k = 0; k < K; k++) part[k] += chain_wait(chain + k * stride + i, stall);
+    } else {
+        const uint32_t group = tile >> 8, first = group << 8;
+        if (first + threadIdx.x < tile)
+            for (int k = 0; k < K; k++) part[k] = chain_wait(chain + k * stride + first + threadIdx.x, stall);
+        if ((tile & 255u) == 255u) {   // the last of its group: the group's totals must not wait for the groups in front
+            uint32_t in_group[K];
+            for (int k = 0; k < K; k++) in_group[k] = part[k];
+            chain_block_sums<K>(in_group, sh + 4 * K);
+            if (threadIdx.x == 0)
+                for (int k = 0; k < K; k++)
+                    __hip_atomic_store(chain + k * stride + tiles + group, CHAIN_VALID | (in_group[k] + own[k]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (uint32_t g = threadIdx.x; g < group; g += 256u)
+            for (int k = 0; k < K; k++) part[k] += chain_wait(chain + k * stride + tiles + g, stall);
+    }
+    chain_block_sums<K>(part, sh + 8 * K);
+    for (int k = 0; k < K; k++) {
+        const unsigned long long m = __ballot(flag[k]);
+        uint32_t r = part[k];
+        for (uint32_t w = 0; w < wave; w++) r += sh[4 * k + w];
+        rank[k] = r + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        upto[k] = part[k] + own[k];
+    }
+}
+
 __device__ __forceinline__ uint32_t owner_of(const uint32_t *pool_owner, const uint32_t *owner_map, uint32_t p) {
     const uint32_t raw = pool_owner[p];
     return owner_map ? owner_map[raw] : raw;
 }
 
+// One lane per face position p of the pool. flags[p]: bit i = the face goes on into child i of the node that owns it
+// (0 for the faces of a leaf's list and for the unused tail of the grid). scanned[p] = (number of faces in front of p that
+// go into their child 0, the same for child 1); scanned[bound] = the two totals.
+// The next pool holds, node after node in the order of their lists here, first a node's child-0 list and then its
+// child-1 list, each in the order of the parent's list. With S0, S1 the two sums, a list [start, start + cnt) therefore
+// sends face p to S1[start] + S0[p] (child 0) and to S0[start + cnt] + S1[p] (child 1).
 __global__ __launch_bounds__(256) void k_kd_test(const double *verts, const uint32_t *faces, const uint32_t *pool_face,
                                                  const uint32_t *pool_owner, const uint32_t *owner_map, const uint32_t *st,
-                                                 uint32_t bound, Nodes cur, int axis, uint32_t *flags) {
-    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-    if (p == 0u) flags[2 * (size_t)bound] = 0u;   // the last element of the scan: its exclusive sum is the total
-    if (p >= bound) return;
-    // The flags of an active node's list [start, start + cnt) fill [2 start, 2 start + 2 cnt). The same slice for the
-    // list of a leaf (and for the unused tail of the grid) is {2p, 2p + 1} of its entries: they are cleared here, so
-    // that the array needs no separate fill before the scan.
-    const uint32_t o = p < st[ST_POOL] ? owner_of(pool_owner, owner_map, p) : NONE;
-    if (o == NONE) { flags[2 * (size_t)p] = 0u; flags[2 * (size_t)p + 1] = 0u; return; }   // this face belongs to a leaf
-    const uint32_t start = cur.start[o], cnt = cur.count[o], j = p - start;
-    if ((unsigned long long)start + cnt > st[ST_POOL] || j >= cnt) return;   // never for a consistent level: stay inside the lists
-    double lo[3], hi[3];
-    for (int k = 0; k < 3; k++) { lo[k] = cur.blo[3 * (size_t)o + k]; hi[k] = cur.bhi[3 * (size_t)o + k]; }
-    const uint32_t *f = faces + 3 * (size_t)pool_face[p];
-    const double *s0 = verts + 3 * (size_t)f[0], *s1 = verts + 3 * (size_t)f[1], *s2 = verts + 3 * (size_t)f[2];
-    // child i spans [min + 0.5*i*ext, min + 0.5*(i+1)*ext] on the split axis (js/8-kd_tree.js:1692-1701)
-    const double base = lo[axis], ext = hi[axis] - lo[axis];
-    for (int i = 0; i < 2; i++) {
-        lo[axis] = base + 0.5 * (double)i * ext;
-        hi[axis] = base + 0.5 * (double)(i + 1) * ext;
-        flags[2 * (size_t)start + (size_t)i * cnt + j] = kd_tri_box_overlap(s0, s1, s2, lo, hi) ? 1u : 0u;
+                                                 uint32_t bound, Nodes cur, int axis, uint32_t *flags, uint2 *scanned,
+                                                 uint32_t *chain, uint32_t *stall) {
+    __shared__ uint32_t sh[2 * CHAIN_SHARED_WORDS_PER_FLAG];
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const bool in_grid = p < bound;
+    bool into[2] = {false, false};
+    if (in_grid) {
+        const uint32_t o = p < st[ST_POOL] ? owner_of(pool_owner, owner_map, p) : NONE;
+        if (o != NONE) {   // NONE: this face belongs to a leaf
+            const uint32_t start = cur.start[o], cnt = cur.count[o];
+            // (never false for a consistent level: stay inside the lists)
+            if ((unsigned long long)start + cnt <= st[ST_POOL] && p - start < cnt) {
+                double lo[3], hi[3];
+                for (int k = 0; k < 3; k++) { lo[k] = cur.blo[3 * (size_t)o + k]; hi[k] = cur.bhi[3 * (size_t)o + k]; }
+                const uint32_t *f = faces + 3 * (size_t)pool_face[p];
+                const double *s0 = verts + 3 * (size_t)f[0], *s1 = verts + 3 * (size_t)f[1], *s2 = verts + 3 * (size_t)f[2];
+                // child i spans [min + 0.5*i*ext, min + 0.5*(i+1)*ext] on the split axis (js/8-kd_tree.js:1692-1701)
+                const double base = lo[axis], ext = hi[axis] - lo[axis];
+                for (int i = 0; i < 2; i++) {
+                    lo[axis] = base + 0.5 * (double)i * ext;
+                    hi[axis] = base + 0.5 * (double)(i + 1) * ext;
+                    into[i] = kd_tri_box_overlap(s0, s1, s2, lo, hi);
+                }
+            }
+        }
+        flags[p] = (into[0] ? 1u : 0u) | (into[1] ? 2u : 0u);
     }
+    uint32_t rank[2], upto[2];
+    chained_ranks<2>(chain, into, sh, stall, rank, upto);
+    if (in_grid) scanned[p] = make_uint2(rank[0], rank[1]);
+    if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0u) scanned[bound] = make_uint2(upto[0], upto[1]);
 }
 
 __device__ __forceinline__ void kd_scatter(uint32_t block, const uint32_t *pool_face, const uint32_t *pool_owner, const uint32_t *owner_map,
                                            const uint32_t *st, uint32_t bound, const Nodes &cur, const uint32_t *flags,
-                                           const uint32_t *scanned, uint32_t next_cap, uint32_t *next_face, uint32_t *next_owner) {
+                                           const uint2 *scanned, uint32_t next_cap, uint32_t *next_face, uint32_t *next_owner) {
     const uint32_t p = block * 256 + threadIdx.x;
     if (p >= min(st[ST_POOL], bound)) return;
+    const uint32_t into = flags[p];
+    if (into == 0u) return;   // (set only for a face of an active node's list)
     const uint32_t o = owner_of(pool_owner, owner_map, p);
-    if (o == NONE) return;
-    const uint32_t start = cur.start[o], cnt = cur.count[o], j = p - start;
-    if ((unsigned long long)start + cnt > st[ST_POOL] || j >= cnt) return;
-    for (uint32_t i = 0; i < 2; i++) {
-        const size_t e = 2 * (size_t)start + (size_t)i * cnt + j;
-        if (flags[e]) {
-            const uint32_t dst = scanned[e];
-            if (dst < next_cap) { next_face[dst] = pool_face[p]; next_owner[dst] = 2 * o + i; }
-        }
+    const uint32_t start = cur.start[o], cnt = cur.count[o];
+    const uint2 mine = scanned[p];
+    if (into & 1u) {
+        const uint32_t dst = scanned[start].y + mine.x;
+        if (dst < next_cap) { next_face[dst] = pool_face[p]; next_owner[dst] = 2 * o; }
+    }
+    if (into & 2u) {
+        const uint32_t dst = scanned[start + cnt].x + mine.y;
+        if (dst < next_cap) { next_face[dst] = pool_face[p]; next_owner[dst] = 2 * o + 1; }
     }
 }
 
 // child c of active node o is child 2*o + c of the level
-__device__ __forceinline__ void kd_classify(uint32_t block, const Nodes &cur, const uint32_t *st, uint32_t bound, const uint32_t *scanned,
+__device__ __forceinline__ void kd_classify(uint32_t block, const Nodes &cur, const uint32_t *st, uint32_t bound, const uint2 *scanned,
                                             int child_depth, int max_depth, uint32_t *child_start, uint32_t *child_count,
                                             uint32_t *child_flag) {
     const uint32_t t = block * 256 + threadIdx.x;
-    if (t == 0u) child_flag[2 * (size_t)bound] = 0u;   // the last element of the scan
     if (t >= 2 * bound) return;
     if (t >= 2 * st[ST_ACTIVE]) { child_flag[t] = 0u; return; }
     const uint32_t o = t >> 1, c = t & 1u;
     const uint32_t start = cur.start[o], cnt = cur.count[o];
     if ((unsigned long long)start + cnt > st[ST_POOL]) { child_start[t] = 0u; child_count[t] = 0u; child_flag[t] = 0u; return; }
-    const size_t e0 = 2 * (size_t)start + (size_t)c * cnt;
-    const uint32_t first = scanned[e0], n = scanned[e0 + cnt] - first;
+    const uint2 a = scanned[start], b = scanned[start + cnt];
+    const uint32_t n0 = b.x - a.x, n1 = b.y - a.y;
+    const uint32_t first = a.x + a.y + (c ? n0 : 0u), n = c ? n1 : n0;
     child_start[t] = first;
     child_count[t] = n;
     child_flag[t] = (n > 4u && child_depth < max_depth) ? 1u : 0u;   // js/8-kd_tree.js:1683
 }
 
-// what a level produced = the sizes of the next one. The children of the root and of every third level below it open
-// new 16-slot blocks. A list that would run out stops the build here (sizes 0) and is named in the flags.
 // both read the exclusive sums over the flags and nothing of each other: one launch, the first blocks scatter
 __global__ __launch_bounds__(256) void k_kd_scatter_classify(uint32_t scatter_blocks, const uint32_t *pool_face, const uint32_t *pool_owner,
                                                              const uint32_t *owner_map, const uint32_t *st, uint32_t bound_pool,
                                                              uint32_t bound_active, Nodes cur, const uint32_t *flags,
-                                                             const uint32_t *scanned, uint32_t next_cap, uint32_t *next_face,
+                                                             const uint2 *scanned, uint32_t next_cap, uint32_t *next_face,
                                                              uint32_t *next_owner, int child_depth, int max_depth,
                                                              uint32_t *child_start, uint32_t *child_count, uint32_t *child_flag) {
     if (blockIdx.x < scatter_blocks)
@@ -173,17 +281,21 @@ __global__ __launch_bounds__(256) void k_kd_scatter_classify(uint32_t scatter_bl
         kd_classify(blockIdx.x - scatter_blocks, cur, st, bound_active, scanned, child_depth, max_depth, child_start, child_count, child_flag);
 }
 
+// what a level produced = the sizes of the next one, and the lengths of the lists so far. The children of the root and
+// of every third level below it open new 16-slot blocks. A list that would run out stops the build here (sizes 0) and
+// is named in the flags.
 struct Advance {
-    const uint32_t *pool_total, *active_total;   // the last elements of the two exclusive sums of the level
+    const uint2 *pool_total;   // the last element of the exclusive sums over the level's flags
     uint32_t bound_pool, bound_active, cap_pool, cap_nodes, node_cap;
     int next_opens_block;
 };
-__device__ __forceinline__ void kd_advance(const Advance &a, const uint32_t *st, uint32_t *nxt) {
-    const uint32_t *pool_total = a.pool_total, *active_total = a.active_total;
+__device__ __forceinline__ void kd_advance(const Advance &a, uint32_t active_total, uint32_t new_leaves, uint32_t new_pairs,
+                                           uint32_t new_empty, const uint32_t *st, uint32_t *nxt, uint32_t *counters) {
     const uint32_t bound_pool = a.bound_pool, bound_active = a.bound_active, cap_pool = a.cap_pool, cap_nodes = a.cap_nodes,
                    node_cap = a.node_cap;
     const int next_opens_block = a.next_opens_block;
-    uint32_t n_pool = *pool_total, n_active = *active_total, over = st[ST_OVER];
+    const uint2 totals = *a.pool_total;
+    uint32_t n_pool = totals.x + totals.y, n_active = active_total, over = st[ST_OVER];
     const uint32_t used = st[ST_USED];
     // this level was larger than the grids it ran on: it was processed in part only, nothing may build on it
     if (st[ST_POOL] > bound_pool || st[ST_ACTIVE] > bound_active) over |= 16u;
@@ -197,6 +309,9 @@ __device__ __forceinline__ void kd_advance(const Advance &a, const uint32_t *st,
     if (used_next > node_cap) over |= 4u;
     if (over) n_pool = n_active = 0u;
     nxt[ST_POOL] = n_pool; nxt[ST_ACTIVE] = n_active; nxt[ST_BLOCK] = used; nxt[ST_USED] = over ? used : used_next; nxt[ST_OVER] = over;
+    // the lists of leaves and of (heap index, metadata) pairs grow level by level: the next level appends here
+    nxt[ST_LEAVES] = st[ST_LEAVES] + new_leaves; nxt[ST_PAIRS] = st[ST_PAIRS] + new_pairs; nxt[ST_EMPTY] = st[ST_EMPTY] + new_empty;
+    counters[C_LEAVES] = nxt[ST_LEAVES]; counters[C_PAIRS] = nxt[ST_PAIRS]; counters[C_EMPTY] = nxt[ST_EMPTY];
 }
 
 struct EmitOut {
@@ -211,28 +326,43 @@ struct EmitOut {
 
 __global__ __launch_bounds__(256) void k_kd_emit(Nodes cur, Nodes nxt, const uint32_t *st, uint32_t bound, uint32_t next_cap_nodes,
                                                  int axis, int opens_block, const uint32_t *child_start,
-                                                 const uint32_t *child_count, const uint32_t *child_flag, const uint32_t *child_scan,
+                                                 const uint32_t *child_count, const uint32_t *child_flag,
                                                  const uint32_t *next_face, uint32_t pool_cap, uint32_t *owner_map, EmitOut out,
-                                                 Advance adv, uint32_t *st_next) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t == 0u) kd_advance(adv, st, st_next);   // the sizes of the next level (the sums of this one are complete)
-    if (t >= 2 * min(st[ST_ACTIVE], bound)) return;
+                                                 Advance adv, uint32_t *st_next, uint32_t *chain) {
+    __shared__ uint32_t sh[4 * CHAIN_SHARED_WORDS_PER_FLAG];
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const bool live = t < 2 * min(st[ST_ACTIVE], bound);
+    const uint32_t c = t & 1u, n = live ? child_count[t] : 0u;
+    const bool splits = live && child_flag[t] != 0u;
+    // what this child adds to the lists: itself as a node of the next level, a leaf, its parent's record (written by
+    // the first child), an empty leaf's record. Its places are its ranks among the lanes of the launch that add the same:
+    // no atomics (those on one address are served one after the other, a microsecond per hundred waves)
+    const bool adds[4] = {splits, live && !splits && n != 0u, live && c == 0u, live && !splits && n == 0u};
+    uint32_t rank[4], upto[4];
+    chained_ranks<4>(chain, adds, sh, &out.counters[C_STALL], rank, upto);
+    // the sizes of the next level (the sums of this one are complete in the last workgroup)
+    if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0u)
+        kd_advance(adv, upto[0], upto[1], upto[2] + upto[3], upto[3], st, st_next, out.counters);
+    if (!live) return;
     const uint32_t block_base = st[ST_BLOCK];
-    const uint32_t o = t >> 1, c = t & 1u;
+    const uint32_t o = t >> 1;
     const uint32_t pos = cur.pos[o], heap = cur.heap[o];
     // treelet layout (kd_build.cpp: relayout_treelets): a 16-slot block holds a pair, its four children and eight
     // grandchildren; the pairs below the third level open blocks of their own
     const uint32_t kids = opens_block ? block_base + 16u * o : (pos & ~15u) + 2u * (pos & 15u) + 2u;
     const float flo = cur.flo[3 * (size_t)o + axis], fhi = cur.fhi[3 * (size_t)o + axis];
     const float split = flo + 0.5f * (fhi - flo);   // the shader's plane (js/8-kd_tree.js:873, :885)
+    const uint32_t cpos = kids + c, cheap = 2u * heap + 1u + c;
+    const bool is_empty = adds[3];
+    // pair records: parents' and empty leaves' share one list, in lane order
+    const uint32_t pi_parent = st[ST_PAIRS] + rank[2] + rank[3], pi_empty = pi_parent + (c == 0u ? 1u : 0u);
+    const uint32_t li = st[ST_LEAVES] + rank[1];
     if (c == 0u) {
         if (pos < out.node_cap) out.nodes[pos] = KdNodeDev{split, T_INTERNAL | ((uint32_t)axis << 28) | kids};
-        const uint32_t pi = atomicAdd(&out.counters[C_PAIRS], 1u);
-        if (pi < out.cap_pairs) out.pairs[pi] = make_uint2(heap, T_INTERNAL);
+        if (pi_parent < out.cap_pairs) out.pairs[pi_parent] = make_uint2(heap, T_INTERNAL);
     }
-    const uint32_t cpos = kids + c, cheap = 2u * heap + 1u + c, n = child_count[t];
-    if (child_flag[t]) {
-        const uint32_t idx = child_scan[t];
+    if (splits) {
+        const uint32_t idx = rank[0];
         owner_map[t] = idx;
         if (idx >= next_cap_nodes) return;
         const double base = cur.blo[3 * (size_t)o + axis], ext = cur.bhi[3 * (size_t)o + axis] - base;
@@ -253,15 +383,12 @@ __global__ __launch_bounds__(256) void k_kd_emit(Nodes cur, Nodes nxt, const uin
         return;
     }
     owner_map[t] = NONE;
-    if (n == 0u) {
+    if (is_empty) {
         if (cpos < out.node_cap) out.nodes[cpos] = KdNodeDev{0.0f, T_EMPTY};
-        const uint32_t pi = atomicAdd(&out.counters[C_PAIRS], 1u);
-        if (pi < out.cap_pairs) out.pairs[pi] = make_uint2(cheap, T_EMPTY);
-        atomicAdd(&out.counters[C_EMPTY], 1u);
+        if (pi_empty < out.cap_pairs) out.pairs[pi_empty] = make_uint2(cheap, T_EMPTY);
         return;
     }
     // leaf: the first four faces of the list, the rest is dropped (KdLeaf, js/8-kd_tree.js:1610-1617)
-    const uint32_t li = atomicAdd(&out.counters[C_LEAVES], 1u);
     if (li >= out.cap_leaves) return;
     const uint32_t keep = n < 4u ? n : 4u;
     out.leaf_heap[li] = cheap;
@@ -315,7 +442,8 @@ __global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap,
             ltag[first + k] = TriTag{t.mat, t.face, code, 0u};
         }
     }
-    const uint32_t pi = atomicAdd(&counters[C_PAIRS], 1u);
+    // the leaves' pair records follow those of the inner nodes and empty leaves, in leaf order
+    const uint32_t pi = counters[C_PAIRS] + number;
     if (pi < cap_pairs) pairs[pi] = make_uint2(heap, T_LEAF | number);
 }
 
@@ -333,6 +461,7 @@ __global__ void k_kd_init_root(const unsigned long long *box_keys, Nodes cur, ui
     }
     cur.heap[0] = 0u; cur.start[0] = 0u; cur.count[0] = n_faces; cur.pos[0] = 0u;
     st[ST_POOL] = n_faces; st[ST_ACTIVE] = 1u; st[ST_BLOCK] = 16u; st[ST_USED] = 32u; st[ST_OVER] = 0u;
+    st[ST_LEAVES] = 0u; st[ST_PAIRS] = 0u; st[ST_EMPTY] = 0u;
 }
 
 #define KCK(call)                                                              \
@@ -353,6 +482,8 @@ int grow(T *&p, size_t n, std::string &err) {
 }
 
 inline dim3 blocks_for(uint64_t n) { return dim3((unsigned)std::max<uint64_t>((n + 255) / 256, 1)); }
+// words a launch over n lanes needs for its chained sums (see chained_ranks)
+inline size_t chain_words(uint64_t n, int flags) { const size_t t = blocks_for(n).x; return (size_t)flags * (t + (t + 255) / 256); }
 
 }  // namespace
 
@@ -360,8 +491,8 @@ GpuKdBuilder::~GpuKdBuilder() { release(); }
 
 void GpuKdBuilder::release() {
     void *ptrs[] = {d_verts, d_faces, d_face_mat, pool_face[0], pool_face[1], pool_owner[0], pool_owner[1], flags, scanned,
-                    child_flag, child_scan, child_count, child_start, owner_map, code_count, code_scan, leaf_heap, leaf_count,
-                    leaf_pos, leaf_faces, counters, lstate, scan_tmp, tree.nodes, tree.tris, tree.lgeo, tree.ltag, tree.path_slot, tree.pairs,
+                    child_flag, child_count, child_start, owner_map, code_count, code_scan, leaf_heap, leaf_count,
+                    leaf_pos, leaf_faces, counters, lstate, scan_tmp, chain, tree.nodes, tree.tris, tree.lgeo, tree.ltag, tree.path_slot, tree.pairs,
                     tree.leaves};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -395,7 +526,7 @@ int GpuKdBuilder::reserve(int64_t n_verts, int64_t n_faces, std::string &err) {
     if (want_pool > cap_pool) {
         for (int i = 0; i < 2; i++)
             if (grow(pool_face[i], want_pool, err) || grow(pool_owner[i], want_pool, err)) return -1;
-        if (grow(flags, 2 * (size_t)want_pool + 1, err) || grow(scanned, 2 * (size_t)want_pool + 1, err)) return -1;
+        if (grow(flags, (size_t)want_pool + 1, err) || grow(scanned, (size_t)want_pool + 1, err)) return -1;
         cap_pool = want_pool;
     }
     const uint32_t want_nodes = (uint32_t)std::min<int64_t>(std::max<int64_t>(n_faces * 4, 1 << 16) * (int64_t)grow_nodes, 1 << 26);
@@ -407,8 +538,7 @@ int GpuKdBuilder::reserve(int64_t n_verts, int64_t n_faces, std::string &err) {
                 grow(l.pos, want_nodes, err))
                 return -1;
         const size_t nc = 2 * (size_t)want_nodes + 1;
-        if (grow(child_flag, nc, err) || grow(child_scan, nc, err) || grow(child_count, nc, err) || grow(child_start, nc, err) ||
-            grow(owner_map, nc, err))
+        if (grow(child_flag, nc, err) || grow(child_count, nc, err) || grow(child_start, nc, err) || grow(owner_map, nc, err))
             return -1;
         cap_level_nodes = want_nodes;
     }
@@ -427,14 +557,12 @@ int GpuKdBuilder::reserve(int64_t n_verts, int64_t n_faces, std::string &err) {
     if (!code_count) {
         if (grow(code_count, (size_t)CODES + 1, err) || grow(code_scan, (size_t)CODES + 1, err) || grow(tree.path_slot, (size_t)CODES, err)) return -1;
     }
-    // temporary storage of the scans: the largest of the three uses
-    size_t need = 0, b = 0;
-    KCK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, flags, scanned, (int)(2 * (size_t)cap_pool + 1)));
-    need = std::max(need, b);
-    KCK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, child_flag, child_scan, (int)(2 * (size_t)cap_level_nodes + 1)));
-    need = std::max(need, b);
-    KCK(hipcub::DeviceScan::ExclusiveSum(nullptr, b, code_count, code_scan, (int)(CODES + 1)));
-    need = std::max(need, b);
+    // states of the chained sums: two launches per level
+    const size_t want_chain = (size_t)MAX_BUILD_LEVELS * (chain_words(cap_pool, 2) + chain_words(2 * (uint64_t)cap_level_nodes, 4));
+    if (want_chain > cap_chain) { if (grow(chain, want_chain, err)) return -1; cap_chain = want_chain; }
+    // temporary storage of the library scan that numbers the leaves
+    size_t need = 0;
+    KCK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, code_count, code_scan, (int)(CODES + 1)));
     if (need > scan_tmp_bytes) {
         if (scan_tmp) KCK(hipFree(scan_tmp));
         scan_tmp = nullptr;
@@ -521,6 +649,15 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     }
     int side = 0, levels = 0;
     uint32_t grid_pool[MAX_BUILD_LEVELS], grid_active[MAX_BUILD_LEVELS];
+    // the chained sums of a launch start from zeroed words: all of them at once when the grids are known beforehand
+    size_t chain_used = 0;
+    if (predicted) {
+        size_t words = 0;
+        for (int d = 0; d < hist_levels; d++)
+            words += chain_words(with_margin(hist_pool[d], 4096, cap_pool), 2) +
+                     chain_words(2 * (uint64_t)with_margin(hist_active[d], 256, cap_level_nodes), 4);
+        KCK(hipMemsetAsync(chain, 0, words * sizeof(uint32_t), s));
+    }
     EmitOut out{tree.nodes, cap_node_slots, tree.pairs, cap_pairs, leaf_heap, leaf_count, leaf_pos, leaf_faces, cap_leaves, counters};
 
     for (int d = 0; predicted ? d < hist_levels : n_active > 0; d++) {   // d = depth of the active nodes, root = 0 (the reference counts from 1)
@@ -531,26 +668,24 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
         const uint32_t ga = predicted ? with_margin(hist_active[d], 256, cap_level_nodes) : n_active;
         grid_pool[d] = gp; grid_active[d] = ga;
         uint32_t *st = lstate + (size_t)d * ST_WORDS;
-        const size_t n_flags = 2 * (size_t)gp + 1, n_child = 2 * (size_t)ga + 1;
-        hipLaunchKernelGGL(k_kd_test, blocks_for(gp), dim3(256), 0, s, d_verts, d_faces, pool_face[side], pool_owner[side], omap,
-                           st, gp, cur, axis, flags);
-        size_t tmp = scan_tmp_bytes;
-        KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, flags, scanned, (int)n_flags, s));
+        uint32_t *chain_test = chain + chain_used, *chain_emit = chain_test + chain_words(gp, 2);
+        chain_used += chain_words(gp, 2) + chain_words(2 * (uint64_t)ga, 4);
+        if (!predicted) KCK(hipMemsetAsync(chain_test, 0, (size_t)(chain + chain_used - chain_test) * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_kd_test, blocks_for(gp), dim3(256), 0, s, d_verts, d_faces, pool_face[side], pool_owner[side],
+                           omap, st, gp, cur, axis, flags, scanned, chain_test, counters + C_STALL);
         const unsigned sb = blocks_for(gp).x;
         hipLaunchKernelGGL(k_kd_scatter_classify, dim3(sb + blocks_for(2 * (uint64_t)ga).x), dim3(256), 0, s, sb, pool_face[side],
                            pool_owner[side], omap, st, gp, ga, cur, flags, scanned, cap_pool, pool_face[side ^ 1], pool_owner[side ^ 1],
                            d + 2, max_depth, child_start, child_count, child_flag);
-        tmp = scan_tmp_bytes;
-        KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, child_flag, child_scan, (int)n_child, s));
         // the children of the root and of every third level below it open new 16-slot blocks
         const bool opens_block = (d % 3 == 0);
         // the emit kernel writes owner_map, which k_kd_test / k_kd_scatter of this level read: they are done (same stream)
         hipLaunchKernelGGL(k_kd_emit, blocks_for(2 * (uint64_t)ga), dim3(256), 0, s, cur, nxt, st, ga, cap_level_nodes, axis,
-                           opens_block ? 1 : 0, child_start, child_count, child_flag, child_scan, pool_face[side ^ 1],
+                           opens_block ? 1 : 0, child_start, child_count, child_flag, pool_face[side ^ 1],
                            cap_pool, owner_map, out,
-                           Advance{scanned + 2 * (size_t)gp, child_scan + 2 * (size_t)ga, gp, ga, cap_pool, cap_level_nodes,
+                           Advance{scanned + gp, gp, ga, cap_pool, cap_level_nodes,
                                    predicted ? cap_node_slots : 0xffffffffu, ((d + 1) % 3 == 0) ? 1 : 0},
-                           st + ST_WORDS);
+                           st + ST_WORDS, chain_emit);
         KCK(hipGetLastError());
         levels = d + 1;
         if (!predicted) {
@@ -601,6 +736,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     KCK(hipEventRecord(ev1, s));
     KCK(hipStreamSynchronize(s));
     const uint32_t n_leaves = h_counters[C_LEAVES];
+    if (h_counters[C_STALL]) { err = "device k-d build: a workgroup waited for the flag count of another that never reported"; return -1; }
     if (predicted) {
         // did every bound hold? A level larger than its grid was only partly processed: everything after it is void
         const uint32_t *last = h_lstate + (size_t)levels * ST_WORDS;
@@ -614,7 +750,8 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     if (n_leaves > cap_leaves) { err = "leaf list too small"; grow_leaves *= 2; return 1; }
     const unsigned long long total = *h_total;
     if ((uint32_t)(total >> 32) != n_leaves) { err = "device k-d build: two leaves share a path code"; return -1; }
-    if (h_counters[C_PAIRS] > cap_pairs) { err = "node list too small"; grow_leaves *= 2; return 1; }
+    // (the leaves' records follow those of the inner nodes and empty leaves)
+    if ((uint64_t)h_counters[C_PAIRS] + n_leaves > cap_pairs) { err = "node list too small"; grow_leaves *= 2; return 1; }
     for (int k = 0; k < 6; k++) tree.root_box[k] = key_value(hk[k]);
     tree.n_internal = 0;
     int real_levels = 0;   // a tree that got shallower leaves the last predicted levels without nodes
@@ -632,7 +769,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     tree.n_leaves = n_leaves;
     tree.n_leaf = n_leaves;
     tree.n_empty = h_counters[C_EMPTY];
-    tree.n_nodes = h_counters[C_PAIRS];
+    tree.n_nodes = h_counters[C_PAIRS] + n_leaves;
     tree.n_node_slots = hist_used;
     float ms = 0;
     KCK(hipEventElapsedTime(&ms, ev0, ev1));
