@@ -76,7 +76,8 @@ private:
     uint2 *scanned = nullptr;                                // cap_pool + 1: faces in front that go on into child 0 / child 1
     uint32_t *child_flag = nullptr;                          // 2 * cap_level_nodes + 1
     uint32_t *child_count = nullptr, *child_start = nullptr, *owner_map = nullptr;
-    unsigned long long *code_count = nullptr, *code_scan = nullptr;   // 2^PATH_BITS + 1
+    unsigned long long *leaf_bits = nullptr;                 // per block of 64 path codes: mask of the leaves, then their face counts
+    unsigned long long *block_scan = nullptr;                // (leaves, faces) in front of each block
     uint32_t *leaf_heap = nullptr, *leaf_count = nullptr, *leaf_pos = nullptr, *leaf_faces = nullptr;
     uint32_t cap_leaves = 0, cap_pairs = 0;
     uint32_t *counters = nullptr;                            // device: leaves, pairs, empties, root box keys

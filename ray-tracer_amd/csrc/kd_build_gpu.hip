@@ -60,23 +60,35 @@ inline unsigned long long host_order_key(double x) {
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-// root box: x from vertex 0, y from vertex 1, z from vertex 2 of each face (js/8-kd_tree.js:1657-1669)
+// root box: x from vertex 0, y from vertex 1, z from vertex 2 of each face (js/8-kd_tree.js:1657-1669).
+// A few workgroups stride over the faces and end with one atomic pair per coordinate each: atomics on one address are
+// served one after the other (about 10 ns each), so one pair per wave of a face-sized grid would cost more than the rest.
+constexpr unsigned ROOT_BOX_BLOCKS = 64;
 __global__ __launch_bounds__(256) void k_kd_root_box(const double *verts, const uint32_t *faces, uint32_t n_faces,
                                                      unsigned long long *keys /* lo xyz, hi xyz */) {
-    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    __shared__ unsigned long long s_lo[3][4], s_hi[3][4];
+    unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};
+    for (uint32_t f = blockIdx.x * 256 + threadIdx.x; f < n_faces; f += gridDim.x * 256) {
+        for (int k = 0; k < 3; k++) {
+            const unsigned long long c = order_key(verts[3 * (size_t)faces[3 * (size_t)f + k] + k]);
+            lo[k] = c < lo[k] ? c : lo[k];
+            hi[k] = c > hi[k] ? c : hi[k];
+        }
+    }
     for (int k = 0; k < 3; k++) {
-        // one atomic pair per wave: atomics on one address are served one after the other
-        unsigned long long lo = ~0ull, hi = 0ull;
-        if (f < n_faces) lo = hi = order_key(verts[3 * (size_t)faces[3 * (size_t)f + k] + k]);
         for (int o = 32; o; o >>= 1) {
-            const unsigned long long a = (unsigned long long)__shfl_xor((long long)lo, o), b = (unsigned long long)__shfl_xor((long long)hi, o);
-            lo = a < lo ? a : lo;
-            hi = b > hi ? b : hi;
+            const unsigned long long a = (unsigned long long)__shfl_xor((long long)lo[k], o), b = (unsigned long long)__shfl_xor((long long)hi[k], o);
+            lo[k] = a < lo[k] ? a : lo[k];
+            hi[k] = b > hi[k] ? b : hi[k];
         }
-        if ((threadIdx.x & 63u) == 0u && lo <= hi) {
-            atomicMin(&keys[k], lo);
-            atomicMax(&keys[3 + k], hi);
-        }
+        if ((threadIdx.x & 63u) == 0u) { s_lo[k][threadIdx.x >> 6] = lo[k]; s_hi[k][threadIdx.x >> 6] = hi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3u) {
+        const int k = (int)threadIdx.x;
+        unsigned long long a = s_lo[k][0], b = s_hi[k][0];
+        for (int w = 1; w < 4; w++) { a = s_lo[k][w] < a ? s_lo[k][w] : a; b = s_hi[k][w] > b ? s_hi[k][w] : b; }
+        if (a <= b) { atomicMin(&keys[k], a); atomicMax(&keys[3 + k], b); }
     }
 }
 
@@ -408,27 +420,54 @@ __device__ __forceinline__ uint32_t code_of_heap(uint32_t heap) {
 
 // Leaves are numbered in the reference's creation order: depth first, upper child first. Of two leaves the one in
 // the upper subtree of their common ancestor comes first, i.e. the one with the larger path code (the codes are
-// prefix-free). code_count is indexed by the complement of the code, so that an exclusive sum over it runs in that order:
-// low word = faces kept by the leaves before this one (its first slot in the leaf-ordered triangle table), high word =
-// number of leaves before it (its index).
+// prefix-free). With key = the complement of the code, a leaf's index is the number of leaves with a smaller key and its
+// first slot in the leaf-ordered triangle table the number of faces those keep. The 2^PATH_BITS keys are cut into blocks
+// of 64: per block a 64-bit mask of the keys that are leaves and 64 two-bit fields with their face counts - 1 (3 MB to
+// clear instead of a 64 MB table), an exclusive sum over the blocks' (leaves, faces) totals, and bit counts inside a block.
+constexpr uint32_t CODE_BLOCKS = CODES / 64u;
+
+// sum of the 32 two-bit fields of x
+__host__ __device__ __forceinline__ uint32_t sum_of_pairs(unsigned long long x) {
+    return (uint32_t)__builtin_popcountll(x & 0x5555555555555555ull) + 2u * (uint32_t)__builtin_popcountll(x & 0xaaaaaaaaaaaaaaaaull);
+}
+
 __global__ __launch_bounds__(256) void k_kd_leaf_mark(const uint32_t *leaf_heap, const uint32_t *leaf_count, const uint32_t *n_leaves,
-                                                      uint32_t bound, unsigned long long *code_count) {
+                                                      uint32_t bound, unsigned long long *mask, unsigned long long *fields) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= min(*n_leaves, bound)) return;
-    const uint32_t key = ~code_of_heap(leaf_heap[i]) & (CODES - 1u);
-    code_count[key] = (unsigned long long)leaf_count[i] | (1ull << 32);
+    const uint32_t key = ~code_of_heap(leaf_heap[i]) & (CODES - 1u), b = key >> 6, bit = key & 63u;
+    atomicOr(&mask[b], 1ull << bit);
+    atomicOr(&fields[2 * (size_t)b + (bit >> 5)], (unsigned long long)((leaf_count[i] - 1u) & 3u) << (2u * (bit & 31u)));
 }
+
+// input of the exclusive sum: leaves << 32 | faces of a block of keys; one more element (0) so that the last sum is the total
+struct LeafBlockTotal {
+    const unsigned long long *mask, *fields;
+    __host__ __device__ __forceinline__ unsigned long long operator()(uint32_t b) const {
+        if (b >= CODE_BLOCKS) return 0ull;
+        const uint32_t n = (uint32_t)__builtin_popcountll(mask[b]);
+        return ((unsigned long long)n << 32) | (unsigned long long)(n + sum_of_pairs(fields[2 * (size_t)b]) + sum_of_pairs(fields[2 * (size_t)b + 1]));
+    }
+};
+using LeafBlockTotals = hipcub::TransformInputIterator<unsigned long long, LeafBlockTotal, hipcub::CountingInputIterator<uint32_t>>;
 
 __global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap, const uint32_t *leaf_count, const uint32_t *leaf_pos,
                                                       const uint32_t *leaf_faces, const uint32_t *n_leaves, uint32_t bound,
-                                                      const unsigned long long *code_scan, const TriDev *tris, uint32_t n_tris, KdNodeDev *nodes,
+                                                      const unsigned long long *mask, const unsigned long long *fields,
+                                                      const unsigned long long *block_scan, const TriDev *tris, uint32_t n_tris, KdNodeDev *nodes,
                                                       uint32_t node_cap, TriGeo *lgeo, TriTag *ltag, uint32_t cap_slots, uint32_t *path_slot,
                                                       int32_t *leaves, uint2 *pairs, uint32_t cap_pairs, uint32_t *counters) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= min(*n_leaves, bound)) return;
     const uint32_t heap = leaf_heap[i], code = code_of_heap(heap), cnt = leaf_count[i];
-    const unsigned long long x = code_scan[~code & (CODES - 1u)];
-    const uint32_t first = (uint32_t)x, number = (uint32_t)(x >> 32);
+    const uint32_t key = ~code & (CODES - 1u), b = key >> 6, bit = key & 63u;
+    const unsigned long long before = block_scan[b];
+    // leaves with a smaller key in this block, and what their faces add beyond one each
+    const uint32_t lower = (uint32_t)__builtin_popcountll(mask[b] & ((1ull << bit) - 1ull));
+    const unsigned long long f0 = fields[2 * (size_t)b] & (bit >= 32u ? ~0ull : ((1ull << (2u * bit)) - 1ull));
+    const unsigned long long f1 = bit <= 32u ? 0ull : (fields[2 * (size_t)b + 1] & ((1ull << (2u * (bit - 32u))) - 1ull));
+    const uint32_t number = (uint32_t)(before >> 32) + lower;
+    const uint32_t first = (uint32_t)before + lower + sum_of_pairs(f0) + sum_of_pairs(f1);
     if (leaf_pos[i] < node_cap) nodes[leaf_pos[i]] = KdNodeDev{0.0f, leaf_info(cnt, first)};
     path_slot[code] = first;
     for (uint32_t k = 0; k < 4u; k++) {
@@ -491,7 +530,7 @@ GpuKdBuilder::~GpuKdBuilder() { release(); }
 
 void GpuKdBuilder::release() {
     void *ptrs[] = {d_verts, d_faces, d_face_mat, pool_face[0], pool_face[1], pool_owner[0], pool_owner[1], flags, scanned,
-                    child_flag, child_count, child_start, owner_map, code_count, code_scan, leaf_heap, leaf_count,
+                    child_flag, child_count, child_start, owner_map, leaf_bits, block_scan, leaf_heap, leaf_count,
                     leaf_pos, leaf_faces, counters, lstate, scan_tmp, chain, tree.nodes, tree.tris, tree.lgeo, tree.ltag, tree.path_slot, tree.pairs,
                     tree.leaves};
     for (void *p : ptrs)
@@ -554,15 +593,18 @@ int GpuKdBuilder::reserve(int64_t n_verts, int64_t n_faces, std::string &err) {
     }
     const uint32_t want_pairs = 4 * want_leaves;
     if (want_pairs > cap_pairs) { if (grow(tree.pairs, want_pairs, err)) return -1; cap_pairs = want_pairs; }
-    if (!code_count) {
-        if (grow(code_count, (size_t)CODES + 1, err) || grow(code_scan, (size_t)CODES + 1, err) || grow(tree.path_slot, (size_t)CODES, err)) return -1;
+    if (!leaf_bits) {
+        if (grow(leaf_bits, 3 * (size_t)CODE_BLOCKS, err) || grow(block_scan, (size_t)CODE_BLOCKS + 1, err) || grow(tree.path_slot, (size_t)CODES, err)) return -1;
     }
     // states of the chained sums: two launches per level
     const size_t want_chain = (size_t)MAX_BUILD_LEVELS * (chain_words(cap_pool, 2) + chain_words(2 * (uint64_t)cap_level_nodes, 4));
     if (want_chain > cap_chain) { if (grow(chain, want_chain, err)) return -1; cap_chain = want_chain; }
     // temporary storage of the library scan that numbers the leaves
     size_t need = 0;
-    KCK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, code_count, code_scan, (int)(CODES + 1)));
+    {
+        LeafBlockTotals totals(hipcub::CountingInputIterator<uint32_t>(0u), LeafBlockTotal{leaf_bits, leaf_bits + CODE_BLOCKS});
+        KCK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, totals, block_scan, (int)(CODE_BLOCKS + 1)));
+    }
     if (need > scan_tmp_bytes) {
         if (scan_tmp) KCK(hipFree(scan_tmp));
         scan_tmp = nullptr;
@@ -634,7 +676,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     memset(h_counters, 0, (C_WORDS + 12) * sizeof(uint32_t));
     for (int k = 0; k < 3; k++) { hk[k] = host_order_key(infinity); hk[3 + k] = host_order_key(-infinity); }
     KCK(hipMemcpyAsync(counters, h_counters, (C_WORDS + 12) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_kd_root_box, blocks_for(nf), dim3(256), 0, s, d_verts, d_faces, nf, box_keys);
+    hipLaunchKernelGGL(k_kd_root_box, dim3(std::min(blocks_for(nf).x, ROOT_BOX_BLOCKS)), dim3(256), 0, s, d_verts, d_faces, nf, box_keys);
     hipLaunchKernelGGL(k_kd_make_tris, blocks_for(nf), dim3(256), 0, s, d_verts, d_faces, d_face_mat, nf, tree.tris);
     hipLaunchKernelGGL(k_kd_init_root, dim3(1), dim3(1), 0, s, box_keys, cur, nf, lstate);
     hipLaunchKernelGGL(k_kd_iota, blocks_for(nf), dim3(256), 0, s, pool_face[0], nf);
@@ -721,16 +763,18 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
         grid_leaves = h_counters[C_LEAVES];
         if (grid_leaves > cap_leaves) { err = "leaf list too small"; grow_leaves *= 2; return 1; }
     }
-    KCK(hipMemsetAsync(code_count, 0, ((size_t)CODES + 1) * sizeof(unsigned long long), s));
+    unsigned long long *leaf_mask = leaf_bits, *leaf_fields = leaf_bits + CODE_BLOCKS;
+    KCK(hipMemsetAsync(leaf_bits, 0, 3 * (size_t)CODE_BLOCKS * sizeof(unsigned long long), s));
     hipLaunchKernelGGL(k_kd_leaf_mark, blocks_for(grid_leaves), dim3(256), 0, s, leaf_heap, leaf_count, counters + C_LEAVES, grid_leaves,
-                       code_count);
+                       leaf_mask, leaf_fields);
     size_t tmp = scan_tmp_bytes;
-    KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, code_count, code_scan, (int)(CODES + 1), s));
+    LeafBlockTotals totals(hipcub::CountingInputIterator<uint32_t>(0u), LeafBlockTotal{leaf_mask, leaf_fields});
+    KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, totals, block_scan, (int)(CODE_BLOCKS + 1), s));
     hipLaunchKernelGGL(k_kd_leaf_emit, blocks_for(grid_leaves), dim3(256), 0, s, leaf_heap, leaf_count, leaf_pos, leaf_faces,
-                       counters + C_LEAVES, grid_leaves, code_scan, tree.tris, nf, tree.nodes, cap_node_slots, tree.lgeo, tree.ltag, cap_slots,
+                       counters + C_LEAVES, grid_leaves, leaf_mask, leaf_fields, block_scan, tree.tris, nf, tree.nodes, cap_node_slots, tree.lgeo, tree.ltag, cap_slots,
                        tree.path_slot, tree.leaves, tree.pairs, cap_pairs, counters);
     KCK(hipGetLastError());
-    KCK(hipMemcpyAsync(h_total, code_scan + CODES, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    KCK(hipMemcpyAsync(h_total, block_scan + CODE_BLOCKS, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     KCK(hipMemcpyAsync(h_counters, counters, (C_WORDS + 12) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     KCK(hipMemcpyAsync(h_lstate, lstate, (size_t)(levels + 1) * ST_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     KCK(hipEventRecord(ev1, s));
