@@ -74,11 +74,11 @@ private:
     uint32_t cap_pool = 0;
     uint32_t *flags = nullptr;                               // cap_pool + 1: which children a face goes on into
     uint2 *scanned = nullptr;                                // cap_pool + 1: faces in front that go on into child 0 / child 1
-    uint32_t *child_flag = nullptr;                          // 2 * cap_level_nodes + 1
-    uint32_t *child_count = nullptr, *child_start = nullptr, *owner_map = nullptr;
+    uint32_t *owner_map[2] = {nullptr, nullptr};             // 2 * cap_level_nodes + 1: child of a level -> node of the next, or none
     unsigned long long *leaf_bits = nullptr;                 // per block of 64 path codes: mask of the leaves, then their face counts
     unsigned long long *block_scan = nullptr;                // (leaves, faces) in front of each block
-    uint32_t *leaf_heap = nullptr, *leaf_count = nullptr, *leaf_pos = nullptr, *leaf_faces = nullptr;
+    uint32_t *leaf_heap = nullptr, *leaf_count = nullptr, *leaf_pos = nullptr, *leaf_child = nullptr;
+    uint32_t *child_faces = nullptr;                         // 4 * cap_pairs: the first faces of every child's list
     uint32_t cap_leaves = 0, cap_pairs = 0;
     uint32_t *counters = nullptr;                            // device: leaves, pairs, empties, root box keys
     uint32_t *h_counters = nullptr;                          // pinned

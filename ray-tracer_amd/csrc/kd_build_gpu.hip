@@ -7,16 +7,16 @@
 // the upper child first, js/8-kd_tree.js:1677,:1718); it is restored at the end from the leaves' positions in the tree.
 //
 // One level = all nodes of one depth that still split ("active"). Their face lists sit back to back in a pool.
-//   k_kd_test      one lane per (node, child, face): the child's box, the overlap test, a flag - and the exclusive sum
-//                  over the flags, laid out per node as [flags of child 0][flags of child 1]: a child's list is
+//   k_kd_test      one lane per (node, face): the two child boxes, two overlap tests, two flags - and the exclusive
+//                  sums over either flag, from which every face's place in its child's list follows: a child's list is
 //                  contiguous in the next pool and keeps the parent's order
-//   k_kd_scatter   faces to their places in the next pool
-//   k_kd_classify  one lane per child: size of its list -> splits again / leaf / empty leaf
-//   k_kd_emit      rank of the children that split = their index among the next level's active nodes; node records in
-//                  the treelet layout, boxes of the next level, leaves to a list
+//   k_kd_next      some workgroups move the faces to their places in the next pool; the others take one lane per
+//                  child: size of its list -> splits again / leaf / empty leaf, rank of the children that split = their
+//                  index among the next level's active nodes, node records in the treelet layout, boxes of the next
+//                  level, leaves to a list
 // and at the end the leaves are numbered and their triangles laid out in leaf order (k_kd_leaf_*).
-// The two exclusive sums of a level are computed inside the kernels that produce their input (chained_rank below), so
-// a level is three dependent launches.
+// The exclusive sums of a level are computed inside the kernels that produce their input (chained_ranks below), so a
+// level is two dependent launches.
 #include "kd_build_gpu.h"
 
 #include <hipcub/hipcub.hpp>
@@ -34,7 +34,7 @@ constexpr uint32_t CODES = 1u << PATH_BITS;
 enum { C_LEAVES = 0, C_PAIRS = 1, C_EMPTY = 2, C_STALL = 3, C_WORDS = 4 };
 // state of one level in device memory: what the level before it produced. The kernels of a level read their sizes
 // from here, so that the host can queue all levels without waiting for any of them (grids are sized by bounds).
-enum { ST_POOL = 0, ST_ACTIVE = 1, ST_BLOCK = 2, ST_USED = 3, ST_OVER = 4, ST_LEAVES = 5, ST_PAIRS = 6, ST_EMPTY = 7, ST_WORDS = 8 };
+enum { ST_POOL = 0, ST_ACTIVE = 1, ST_BLOCK = 2, ST_USED = 3, ST_OVER = 4, ST_LEAVES = 5, ST_PAIRS = 6, ST_EMPTY = 7, ST_CHILDREN = 8, ST_WORDS = 12 };
 constexpr int MAX_BUILD_LEVELS = 26;
 
 struct Nodes {
@@ -153,12 +153,13 @@ __device__ __forceinline__ void chain_block_sums(uint32_t (&x)[K], uint32_t *slo
     for (int k = 0; k < K; k++) x[k] = slots[4 * k] + slots[4 * k + 1] + slots[4 * k + 2] + slots[4 * k + 3];
 }
 
-// every lane of the 256-lane workgroup calls it. rank[k] = number of set flags k in front of this lane's, over the whole
+// every lane of the 256-lane workgroups tile = 0 .. tiles - 1 calls it (a tile with a higher number must not be dispatched
+// before one with a lower number). rank[k] = number of set flags k in front of this lane's, over the whole
 // launch; upto[k] = the same including the whole workgroup. sh: K * CHAIN_SHARED_WORDS_PER_FLAG words.
 template <int K>
-__device__ __forceinline__ void chained_ranks(uint32_t *chain, const bool (&flag)[K], uint32_t *sh, uint32_t *stall,
-                                              uint32_t (&rank)[K], uint32_t (&upto)[K]) {
-    const uint32_t tile = blockIdx.x, tiles = gridDim.x, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void chained_ranks(uint32_t *chain, uint32_t tile, uint32_t tiles, const bool (&flag)[K], uint32_t *sh,
+                                              uint32_t *stall, uint32_t (&rank)[K], uint32_t (&upto)[K]) {
+    const uint32_t wave = threadIdx.x >> 6;
     const uint32_t stride = tiles + ((tiles + 255u) >> 8);   // words per flag: own counts, then group totals
     uint32_t own[K], part[K];
     for (int k = 0; k < K; k++) own[k] = flag[k] ? 1u : 0u;
@@ -237,60 +238,9 @@ __global__ __launch_bounds__(256) void k_kd_test(const double *verts, const uint
         flags[p] = (into[0] ? 1u : 0u) | (into[1] ? 2u : 0u);
     }
     uint32_t rank[2], upto[2];
-    chained_ranks<2>(chain, into, sh, stall, rank, upto);
+    chained_ranks<2>(chain, blockIdx.x, gridDim.x, into, sh, stall, rank, upto);
     if (in_grid) scanned[p] = make_uint2(rank[0], rank[1]);
     if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0u) scanned[bound] = make_uint2(upto[0], upto[1]);
-}
-
-__device__ __forceinline__ void kd_scatter(uint32_t block, const uint32_t *pool_face, const uint32_t *pool_owner, const uint32_t *owner_map,
-                                           const uint32_t *st, uint32_t bound, const Nodes &cur, const uint32_t *flags,
-                                           const uint2 *scanned, uint32_t next_cap, uint32_t *next_face, uint32_t *next_owner) {
-    const uint32_t p = block * 256 + threadIdx.x;
-    if (p >= min(st[ST_POOL], bound)) return;
-    const uint32_t into = flags[p];
-    if (into == 0u) return;   // (set only for a face of an active node's list)
-    const uint32_t o = owner_of(pool_owner, owner_map, p);
-    const uint32_t start = cur.start[o], cnt = cur.count[o];
-    const uint2 mine = scanned[p];
-    if (into & 1u) {
-        const uint32_t dst = scanned[start].y + mine.x;
-        if (dst < next_cap) { next_face[dst] = pool_face[p]; next_owner[dst] = 2 * o; }
-    }
-    if (into & 2u) {
-        const uint32_t dst = scanned[start + cnt].x + mine.y;
-        if (dst < next_cap) { next_face[dst] = pool_face[p]; next_owner[dst] = 2 * o + 1; }
-    }
-}
-
-// child c of active node o is child 2*o + c of the level
-__device__ __forceinline__ void kd_classify(uint32_t block, const Nodes &cur, const uint32_t *st, uint32_t bound, const uint2 *scanned,
-                                            int child_depth, int max_depth, uint32_t *child_start, uint32_t *child_count,
-                                            uint32_t *child_flag) {
-    const uint32_t t = block * 256 + threadIdx.x;
-    if (t >= 2 * bound) return;
-    if (t >= 2 * st[ST_ACTIVE]) { child_flag[t] = 0u; return; }
-    const uint32_t o = t >> 1, c = t & 1u;
-    const uint32_t start = cur.start[o], cnt = cur.count[o];
-    if ((unsigned long long)start + cnt > st[ST_POOL]) { child_start[t] = 0u; child_count[t] = 0u; child_flag[t] = 0u; return; }
-    const uint2 a = scanned[start], b = scanned[start + cnt];
-    const uint32_t n0 = b.x - a.x, n1 = b.y - a.y;
-    const uint32_t first = a.x + a.y + (c ? n0 : 0u), n = c ? n1 : n0;
-    child_start[t] = first;
-    child_count[t] = n;
-    child_flag[t] = (n > 4u && child_depth < max_depth) ? 1u : 0u;   // js/8-kd_tree.js:1683
-}
-
-// both read the exclusive sums over the flags and nothing of each other: one launch, the first blocks scatter
-__global__ __launch_bounds__(256) void k_kd_scatter_classify(uint32_t scatter_blocks, const uint32_t *pool_face, const uint32_t *pool_owner,
-                                                             const uint32_t *owner_map, const uint32_t *st, uint32_t bound_pool,
-                                                             uint32_t bound_active, Nodes cur, const uint32_t *flags,
-                                                             const uint2 *scanned, uint32_t next_cap, uint32_t *next_face,
-                                                             uint32_t *next_owner, int child_depth, int max_depth,
-                                                             uint32_t *child_start, uint32_t *child_count, uint32_t *child_flag) {
-    if (blockIdx.x < scatter_blocks)
-        kd_scatter(blockIdx.x, pool_face, pool_owner, owner_map, st, bound_pool, cur, flags, scanned, next_cap, next_face, next_owner);
-    else
-        kd_classify(blockIdx.x - scatter_blocks, cur, st, bound_active, scanned, child_depth, max_depth, child_start, child_count, child_flag);
 }
 
 // what a level produced = the sizes of the next one, and the lengths of the lists so far. The children of the root and
@@ -323,6 +273,7 @@ __device__ __forceinline__ void kd_advance(const Advance &a, uint32_t active_tot
     nxt[ST_POOL] = n_pool; nxt[ST_ACTIVE] = n_active; nxt[ST_BLOCK] = used; nxt[ST_USED] = over ? used : used_next; nxt[ST_OVER] = over;
     // the lists of leaves and of (heap index, metadata) pairs grow level by level: the next level appends here
     nxt[ST_LEAVES] = st[ST_LEAVES] + new_leaves; nxt[ST_PAIRS] = st[ST_PAIRS] + new_pairs; nxt[ST_EMPTY] = st[ST_EMPTY] + new_empty;
+    nxt[ST_CHILDREN] = st[ST_CHILDREN] + 2u * min(st[ST_ACTIVE], bound_active);
     counters[C_LEAVES] = nxt[ST_LEAVES]; counters[C_PAIRS] = nxt[ST_PAIRS]; counters[C_EMPTY] = nxt[ST_EMPTY];
 }
 
@@ -331,52 +282,103 @@ struct EmitOut {
     uint32_t node_cap;
     uint2 *pairs;
     uint32_t cap_pairs;
-    uint32_t *leaf_heap, *leaf_count, *leaf_pos, *leaf_faces;
+    uint32_t *leaf_heap, *leaf_count, *leaf_pos, *leaf_child;
     uint32_t cap_leaves;
+    uint32_t *child_faces;   // the first four faces of every child's list, by the child's number over the whole build
+    uint32_t cap_children;
     uint32_t *counters;
 };
 
-__global__ __launch_bounds__(256) void k_kd_emit(Nodes cur, Nodes nxt, const uint32_t *st, uint32_t bound, uint32_t next_cap_nodes,
-                                                 int axis, int opens_block, const uint32_t *child_start,
-                                                 const uint32_t *child_count, const uint32_t *child_flag,
-                                                 const uint32_t *next_face, uint32_t pool_cap, uint32_t *owner_map, EmitOut out,
-                                                 Advance adv, uint32_t *st_next, uint32_t *chain) {
-    __shared__ uint32_t sh[4 * CHAIN_SHARED_WORDS_PER_FLAG];
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    const bool live = t < 2 * min(st[ST_ACTIVE], bound);
-    const uint32_t c = t & 1u, n = live ? child_count[t] : 0u;
-    const bool splits = live && child_flag[t] != 0u;
+struct LevelIn {
+    const uint32_t *pool_face, *pool_owner, *owner_map;   // owner_map: null at the root level
+    const uint32_t *flags;
+    const uint2 *scanned;
+    const uint32_t *st;
+    uint32_t bound_pool, bound_active;
+    int axis, opens_block, child_depth, max_depth;
+};
+struct LevelOut {
+    uint32_t *next_face, *next_owner, *owner_map;
+    uint32_t next_cap, next_cap_nodes;
+    uint32_t *st_next;
+};
+
+// child c of active node o is child 2 o + c of the level. Its list has n faces and begins at `first` in the next pool.
+__device__ __forceinline__ void child_list(const uint2 a /* sums at the node's first face */, const uint2 b /* behind its last */,
+                                           uint32_t c, uint32_t &first, uint32_t &n) {
+    const uint32_t n0 = b.x - a.x, n1 = b.y - a.y;
+    first = a.x + a.y + (c ? n0 : 0u);
+    n = c ? n1 : n0;
+}
+// js/8-kd_tree.js:1683
+__device__ __forceinline__ bool splits_again(uint32_t n, int child_depth, int max_depth) { return n > 4u && child_depth < max_depth; }
+
+// faces to their places in the next pool; the first four faces of a list that becomes a leaf are also kept by child
+__device__ __forceinline__ void kd_scatter(uint32_t block, const LevelIn &in, const Nodes &cur, const LevelOut &o_, const EmitOut &out) {
+    const uint32_t p = block * 256 + threadIdx.x;
+    if (p >= min(in.st[ST_POOL], in.bound_pool)) return;
+    const uint32_t into = in.flags[p];
+    if (into == 0u) return;   // (set only for a face of an active node's list)
+    const uint32_t o = owner_of(in.pool_owner, in.owner_map, p);
+    const uint32_t start = cur.start[o], cnt = cur.count[o], face = in.pool_face[p];
+    const uint2 mine = in.scanned[p], a = in.scanned[start], b = in.scanned[start + cnt];
+    for (uint32_t c = 0; c < 2u; c++) {
+        if (!(into & (1u << c))) continue;
+        uint32_t first, n;
+        child_list(a, b, c, first, n);
+        const uint32_t r = c ? mine.y - a.y : mine.x - a.x;   // place in the child's list
+        const uint32_t dst = first + r;
+        if (dst < o_.next_cap) { o_.next_face[dst] = face; o_.next_owner[dst] = 2 * o + c; }
+        if (r < 4u && !splits_again(n, in.child_depth, in.max_depth)) {
+            const uint32_t child = in.st[ST_CHILDREN] + 2 * o + c;
+            if (child < out.cap_children) out.child_faces[4 * (size_t)child + r] = face;
+        }
+    }
+}
+
+// One lane per child: size of its list -> splits again / leaf / empty leaf; node records in the treelet layout, boxes of
+// the next level, leaves to a list. tile = number of the workgroup among the `tiles` that do this.
+__device__ __forceinline__ void kd_emit(uint32_t tile, uint32_t tiles, const LevelIn &in, const Nodes &cur, const Nodes &nxt, const LevelOut &o_,
+                                        const EmitOut &out, const Advance &adv, uint32_t *chain, uint32_t *sh) {
+    const uint32_t *st = in.st;
+    const int axis = in.axis;
+    const uint32_t t = tile * 256u + threadIdx.x;
+    const bool live = t < 2 * min(st[ST_ACTIVE], in.bound_active);
+    const uint32_t o = t >> 1, c = t & 1u;
+    uint32_t first = 0, n = 0;
+    if (live) {
+        const uint32_t start = cur.start[o], cnt = cur.count[o];
+        if ((unsigned long long)start + cnt <= st[ST_POOL]) child_list(in.scanned[start], in.scanned[start + cnt], c, first, n);
+    }
+    const bool splits = live && splits_again(n, in.child_depth, in.max_depth);
     // what this child adds to the lists: itself as a node of the next level, a leaf, its parent's record (written by
     // the first child), an empty leaf's record. Its places are its ranks among the lanes of the launch that add the same:
     // no atomics (those on one address are served one after the other, a microsecond per hundred waves)
     const bool adds[4] = {splits, live && !splits && n != 0u, live && c == 0u, live && !splits && n == 0u};
     uint32_t rank[4], upto[4];
-    chained_ranks<4>(chain, adds, sh, &out.counters[C_STALL], rank, upto);
+    chained_ranks<4>(chain, tile, tiles, adds, sh, &out.counters[C_STALL], rank, upto);
     // the sizes of the next level (the sums of this one are complete in the last workgroup)
-    if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0u)
-        kd_advance(adv, upto[0], upto[1], upto[2] + upto[3], upto[3], st, st_next, out.counters);
+    if (tile == tiles - 1u && threadIdx.x == 0u)
+        kd_advance(adv, upto[0], upto[1], upto[2] + upto[3], upto[3], st, o_.st_next, out.counters);
     if (!live) return;
     const uint32_t block_base = st[ST_BLOCK];
-    const uint32_t o = t >> 1;
     const uint32_t pos = cur.pos[o], heap = cur.heap[o];
     // treelet layout (kd_build.cpp: relayout_treelets): a 16-slot block holds a pair, its four children and eight
     // grandchildren; the pairs below the third level open blocks of their own
-    const uint32_t kids = opens_block ? block_base + 16u * o : (pos & ~15u) + 2u * (pos & 15u) + 2u;
+    const uint32_t kids = in.opens_block ? block_base + 16u * o : (pos & ~15u) + 2u * (pos & 15u) + 2u;
     const float flo = cur.flo[3 * (size_t)o + axis], fhi = cur.fhi[3 * (size_t)o + axis];
     const float split = flo + 0.5f * (fhi - flo);   // the shader's plane (js/8-kd_tree.js:873, :885)
     const uint32_t cpos = kids + c, cheap = 2u * heap + 1u + c;
-    const bool is_empty = adds[3];
     // pair records: parents' and empty leaves' share one list, in lane order
     const uint32_t pi_parent = st[ST_PAIRS] + rank[2] + rank[3], pi_empty = pi_parent + (c == 0u ? 1u : 0u);
-    const uint32_t li = st[ST_LEAVES] + rank[1];
     if (c == 0u) {
         if (pos < out.node_cap) out.nodes[pos] = KdNodeDev{split, T_INTERNAL | ((uint32_t)axis << 28) | kids};
         if (pi_parent < out.cap_pairs) out.pairs[pi_parent] = make_uint2(heap, T_INTERNAL);
     }
     if (splits) {
         const uint32_t idx = rank[0];
-        owner_map[t] = idx;
-        if (idx >= next_cap_nodes) return;
+        o_.owner_map[t] = idx;
+        if (idx >= o_.next_cap_nodes) return;
         const double base = cur.blo[3 * (size_t)o + axis], ext = cur.bhi[3 * (size_t)o + axis] - base;
         for (int k = 0; k < 3; k++) {
             nxt.blo[3 * (size_t)idx + k] = cur.blo[3 * (size_t)o + k];
@@ -389,27 +391,34 @@ __global__ __launch_bounds__(256) void k_kd_emit(Nodes cur, Nodes nxt, const uin
         if (c == 0u) nxt.fhi[3 * (size_t)idx + axis] = split;
         else nxt.flo[3 * (size_t)idx + axis] = split;
         nxt.heap[idx] = cheap;
-        nxt.start[idx] = child_start[t];
+        nxt.start[idx] = first;
         nxt.count[idx] = n;
         nxt.pos[idx] = cpos;
         return;
     }
-    owner_map[t] = NONE;
-    if (is_empty) {
+    o_.owner_map[t] = NONE;
+    if (n == 0u) {
         if (cpos < out.node_cap) out.nodes[cpos] = KdNodeDev{0.0f, T_EMPTY};
         if (pi_empty < out.cap_pairs) out.pairs[pi_empty] = make_uint2(cheap, T_EMPTY);
         return;
     }
-    // leaf: the first four faces of the list, the rest is dropped (KdLeaf, js/8-kd_tree.js:1610-1617)
+    // leaf: the first four faces of the list, the rest is dropped (KdLeaf, js/8-kd_tree.js:1610-1617); the faces
+    // themselves are left under the child's number by the lanes that move them (kd_scatter)
+    const uint32_t li = st[ST_LEAVES] + rank[1];
     if (li >= out.cap_leaves) return;
-    const uint32_t keep = n < 4u ? n : 4u;
     out.leaf_heap[li] = cheap;
-    out.leaf_count[li] = keep;
+    out.leaf_count[li] = n < 4u ? n : 4u;
     out.leaf_pos[li] = cpos;
-    for (uint32_t k = 0; k < 4u; k++) {   // (a pool that ran out is noticed by the host after this level: stay inside it)
-        const uint32_t src = child_start[t] + k;
-        out.leaf_faces[4 * (size_t)li + k] = (k < keep && src < pool_cap) ? next_face[src] : NONE;
-    }
+    out.leaf_child[li] = st[ST_CHILDREN] + t;
+}
+
+// The second launch of a level. Moving the faces and making the nodes read the sums over the level's flags and nothing
+// of each other: the first workgroups move, the others make nodes.
+__global__ __launch_bounds__(256) void k_kd_next(uint32_t scatter_blocks, LevelIn in, Nodes cur, Nodes nxt, LevelOut o_, EmitOut out,
+                                                 Advance adv, uint32_t *chain) {
+    __shared__ uint32_t sh[4 * CHAIN_SHARED_WORDS_PER_FLAG];
+    if (blockIdx.x < scatter_blocks) kd_scatter(blockIdx.x, in, cur, o_, out);
+    else kd_emit(blockIdx.x - scatter_blocks, gridDim.x - scatter_blocks, in, cur, nxt, o_, out, adv, chain, sh);
 }
 
 __device__ __forceinline__ uint32_t code_of_heap(uint32_t heap) {
@@ -452,14 +461,15 @@ struct LeafBlockTotal {
 using LeafBlockTotals = hipcub::TransformInputIterator<unsigned long long, LeafBlockTotal, hipcub::CountingInputIterator<uint32_t>>;
 
 __global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap, const uint32_t *leaf_count, const uint32_t *leaf_pos,
-                                                      const uint32_t *leaf_faces, const uint32_t *n_leaves, uint32_t bound,
+                                                      const uint32_t *leaf_child, const uint32_t *child_faces, uint32_t cap_children,
+                                                      const uint32_t *n_leaves, uint32_t bound,
                                                       const unsigned long long *mask, const unsigned long long *fields,
                                                       const unsigned long long *block_scan, const TriDev *tris, uint32_t n_tris, KdNodeDev *nodes,
                                                       uint32_t node_cap, TriGeo *lgeo, TriTag *ltag, uint32_t cap_slots, uint32_t *path_slot,
                                                       int32_t *leaves, uint2 *pairs, uint32_t cap_pairs, uint32_t *counters) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= min(*n_leaves, bound)) return;
-    const uint32_t heap = leaf_heap[i], code = code_of_heap(heap), cnt = leaf_count[i];
+    const uint32_t heap = leaf_heap[i], code = code_of_heap(heap), cnt = leaf_count[i], child = leaf_child[i];
     const uint32_t key = ~code & (CODES - 1u), b = key >> 6, bit = key & 63u;
     const unsigned long long before = block_scan[b];
     // leaves with a smaller key in this block, and what their faces add beyond one each
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap,
     if (leaf_pos[i] < node_cap) nodes[leaf_pos[i]] = KdNodeDev{0.0f, leaf_info(cnt, first)};
     path_slot[code] = first;
     for (uint32_t k = 0; k < 4u; k++) {
-        const uint32_t f = leaf_faces[4 * (size_t)i + k];
+        const uint32_t f = (k < cnt && child < cap_children) ? child_faces[4 * (size_t)child + k] : NONE;
         leaves[4 * (size_t)number + k] = k < cnt ? (int32_t)f : -1;
         if (k < cnt && first + k < cap_slots && f < n_tris) {
             const TriDev t = tris[f];
@@ -500,7 +510,7 @@ __global__ void k_kd_init_root(const unsigned long long *box_keys, Nodes cur, ui
     }
     cur.heap[0] = 0u; cur.start[0] = 0u; cur.count[0] = n_faces; cur.pos[0] = 0u;
     st[ST_POOL] = n_faces; st[ST_ACTIVE] = 1u; st[ST_BLOCK] = 16u; st[ST_USED] = 32u; st[ST_OVER] = 0u;
-    st[ST_LEAVES] = 0u; st[ST_PAIRS] = 0u; st[ST_EMPTY] = 0u;
+    st[ST_LEAVES] = 0u; st[ST_PAIRS] = 0u; st[ST_EMPTY] = 0u; st[ST_CHILDREN] = 0u;
 }
 
 #define KCK(call)                                                              \
@@ -530,8 +540,8 @@ GpuKdBuilder::~GpuKdBuilder() { release(); }
 
 void GpuKdBuilder::release() {
     void *ptrs[] = {d_verts, d_faces, d_face_mat, pool_face[0], pool_face[1], pool_owner[0], pool_owner[1], flags, scanned,
-                    child_flag, child_count, child_start, owner_map, leaf_bits, block_scan, leaf_heap, leaf_count,
-                    leaf_pos, leaf_faces, counters, lstate, scan_tmp, chain, tree.nodes, tree.tris, tree.lgeo, tree.ltag, tree.path_slot, tree.pairs,
+                    owner_map[0], owner_map[1], leaf_bits, block_scan, leaf_heap, leaf_count,
+                    leaf_pos, leaf_child, child_faces, counters, lstate, scan_tmp, chain, tree.nodes, tree.tris, tree.lgeo, tree.ltag, tree.path_slot, tree.pairs,
                     tree.leaves};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -577,14 +587,13 @@ int GpuKdBuilder::reserve(int64_t n_verts, int64_t n_faces, std::string &err) {
                 grow(l.pos, want_nodes, err))
                 return -1;
         const size_t nc = 2 * (size_t)want_nodes + 1;
-        if (grow(child_flag, nc, err) || grow(child_count, nc, err) || grow(child_start, nc, err) || grow(owner_map, nc, err))
-            return -1;
+        if (grow(owner_map[0], nc, err) || grow(owner_map[1], nc, err)) return -1;
         cap_level_nodes = want_nodes;
     }
     const uint32_t want_leaves = (uint32_t)std::min<int64_t>(std::max<int64_t>(n_faces * 8, 1 << 16) * (int64_t)grow_leaves, 1 << 27);
     if (want_leaves > cap_leaves) {
         if (grow(leaf_heap, want_leaves, err) || grow(leaf_count, want_leaves, err) || grow(leaf_pos, want_leaves, err) ||
-            grow(leaf_faces, 4 * (size_t)want_leaves, err) || grow(tree.leaves, 4 * (size_t)want_leaves, err) ||
+            grow(leaf_child, want_leaves, err) || grow(tree.leaves, 4 * (size_t)want_leaves, err) ||
             grow(tree.lgeo, 4 * (size_t)want_leaves, err) || grow(tree.ltag, 4 * (size_t)want_leaves, err))
             return -1;
         cap_leaves = want_leaves;
@@ -592,7 +601,11 @@ int GpuKdBuilder::reserve(int64_t n_verts, int64_t n_faces, std::string &err) {
         cap_slots = 4 * want_leaves;
     }
     const uint32_t want_pairs = 4 * want_leaves;
-    if (want_pairs > cap_pairs) { if (grow(tree.pairs, want_pairs, err)) return -1; cap_pairs = want_pairs; }
+    // (every node but the root is a child: the pairs' bound is the children's)
+    if (want_pairs > cap_pairs) {
+        if (grow(tree.pairs, want_pairs, err) || grow(child_faces, 4 * (size_t)want_pairs, err)) return -1;
+        cap_pairs = want_pairs;
+    }
     if (!leaf_bits) {
         if (grow(leaf_bits, 3 * (size_t)CODE_BLOCKS, err) || grow(block_scan, (size_t)CODE_BLOCKS + 1, err) || grow(tree.path_slot, (size_t)CODES, err)) return -1;
     }
@@ -700,12 +713,13 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
                      chain_words(2 * (uint64_t)with_margin(hist_active[d], 256, cap_level_nodes), 4);
         KCK(hipMemsetAsync(chain, 0, words * sizeof(uint32_t), s));
     }
-    EmitOut out{tree.nodes, cap_node_slots, tree.pairs, cap_pairs, leaf_heap, leaf_count, leaf_pos, leaf_faces, cap_leaves, counters};
+    EmitOut out{tree.nodes, cap_node_slots, tree.pairs, cap_pairs, leaf_heap, leaf_count, leaf_pos, leaf_child, cap_leaves, child_faces, cap_pairs, counters};
 
     for (int d = 0; predicted ? d < hist_levels : n_active > 0; d++) {   // d = depth of the active nodes, root = 0 (the reference counts from 1)
         if (d >= MAX_BUILD_LEVELS - 1) { err = "device k-d build: too many levels"; return -1; }
         const int axis = d % 3;            // js/8-kd_tree.js:1689-1702: x, y, z from the root down
-        const uint32_t *omap = d == 0 ? nullptr : owner_map;
+        // the nodes a level makes get their numbers in one table while the faces still find their owners in the other
+        const uint32_t *omap = d == 0 ? nullptr : owner_map[d & 1];
         const uint32_t gp = predicted ? with_margin(hist_pool[d], 4096, cap_pool) : n_pool;
         const uint32_t ga = predicted ? with_margin(hist_active[d], 256, cap_level_nodes) : n_active;
         grid_pool[d] = gp; grid_active[d] = ga;
@@ -716,18 +730,16 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
         hipLaunchKernelGGL(k_kd_test, blocks_for(gp), dim3(256), 0, s, d_verts, d_faces, pool_face[side], pool_owner[side],
                            omap, st, gp, cur, axis, flags, scanned, chain_test, counters + C_STALL);
         const unsigned sb = blocks_for(gp).x;
-        hipLaunchKernelGGL(k_kd_scatter_classify, dim3(sb + blocks_for(2 * (uint64_t)ga).x), dim3(256), 0, s, sb, pool_face[side],
-                           pool_owner[side], omap, st, gp, ga, cur, flags, scanned, cap_pool, pool_face[side ^ 1], pool_owner[side ^ 1],
-                           d + 2, max_depth, child_start, child_count, child_flag);
         // the children of the root and of every third level below it open new 16-slot blocks
         const bool opens_block = (d % 3 == 0);
-        // the emit kernel writes owner_map, which k_kd_test / k_kd_scatter of this level read: they are done (same stream)
-        hipLaunchKernelGGL(k_kd_emit, blocks_for(2 * (uint64_t)ga), dim3(256), 0, s, cur, nxt, st, ga, cap_level_nodes, axis,
-                           opens_block ? 1 : 0, child_start, child_count, child_flag, pool_face[side ^ 1],
-                           cap_pool, owner_map, out,
+        hipLaunchKernelGGL(k_kd_next, dim3(sb + blocks_for(2 * (uint64_t)ga).x), dim3(256), 0, s, sb,
+                           LevelIn{pool_face[side], pool_owner[side], omap, flags, scanned, st, gp, ga, axis, opens_block ? 1 : 0, d + 2, max_depth},
+                           cur, nxt,
+                           LevelOut{pool_face[side ^ 1], pool_owner[side ^ 1], owner_map[(d + 1) & 1], cap_pool, cap_level_nodes, st + ST_WORDS},
+                           out,
                            Advance{scanned + gp, gp, ga, cap_pool, cap_level_nodes,
                                    predicted ? cap_node_slots : 0xffffffffu, ((d + 1) % 3 == 0) ? 1 : 0},
-                           st + ST_WORDS, chain_emit);
+                           chain_emit);
         KCK(hipGetLastError());
         levels = d + 1;
         if (!predicted) {
@@ -770,7 +782,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     size_t tmp = scan_tmp_bytes;
     LeafBlockTotals totals(hipcub::CountingInputIterator<uint32_t>(0u), LeafBlockTotal{leaf_mask, leaf_fields});
     KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, totals, block_scan, (int)(CODE_BLOCKS + 1), s));
-    hipLaunchKernelGGL(k_kd_leaf_emit, blocks_for(grid_leaves), dim3(256), 0, s, leaf_heap, leaf_count, leaf_pos, leaf_faces,
+    hipLaunchKernelGGL(k_kd_leaf_emit, blocks_for(grid_leaves), dim3(256), 0, s, leaf_heap, leaf_count, leaf_pos, leaf_child, child_faces, cap_pairs,
                        counters + C_LEAVES, grid_leaves, leaf_mask, leaf_fields, block_scan, tree.tris, nf, tree.nodes, cap_node_slots, tree.lgeo, tree.ltag, cap_slots,
                        tree.path_slot, tree.leaves, tree.pairs, cap_pairs, counters);
     KCK(hipGetLastError());
