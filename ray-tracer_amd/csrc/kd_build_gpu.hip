@@ -92,10 +92,15 @@ __global__ __launch_bounds__(256) void k_kd_root_box(const double *verts, const 
     }
 }
 
-// triangles in face order: float32 narrowing of the vertices (js/8-kd_tree.js:2462-2464), edges formed in float32
-__global__ __launch_bounds__(256) void k_kd_make_tris(const double *verts, const uint32_t *faces, const int32_t *face_mat,
-                                                      uint32_t n_faces, TriDev *tris) {
+// Everything a build needs before its first level, in one launch: the triangles in face order - float32 narrowing of
+// the vertices (js/8-kd_tree.js:2462-2464), edges formed in float32 -, the root's face list (every face, in index
+// order, owned by node 0), and two work areas cleared.
+__global__ __launch_bounds__(256) void k_kd_setup(const double *verts, const uint32_t *faces, const int32_t *face_mat, uint32_t n_faces,
+                                                  TriDev *tris, uint32_t *pool_face, uint32_t *pool_owner, unsigned long long *clear_a,
+                                                  size_t n_a, uint32_t *clear_b, size_t n_b) {
     const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = f; i < n_a; i += (size_t)gridDim.x * 256) clear_a[i] = 0ull;
+    for (size_t i = f; i < n_b; i += (size_t)gridDim.x * 256) clear_b[i] = 0u;
     if (f >= n_faces) return;
     float v[3][3];
     for (int j = 0; j < 3; j++)
@@ -106,11 +111,8 @@ __global__ __launch_bounds__(256) void k_kd_make_tris(const double *verts, const
     t.face = (int32_t)f;
     t.pad = 0;
     tris[f] = t;
-}
-
-__global__ __launch_bounds__(256) void k_kd_iota(uint32_t *a, uint32_t n) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) a[i] = i;
+    pool_face[f] = f;
+    pool_owner[f] = 0u;
 }
 
 // ---- exclusive sums over K flags per lane across all workgroups of a launch, in a single pass ----
@@ -690,10 +692,15 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     for (int k = 0; k < 3; k++) { hk[k] = host_order_key(infinity); hk[3 + k] = host_order_key(-infinity); }
     KCK(hipMemcpyAsync(counters, h_counters, (C_WORDS + 12) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_kd_root_box, dim3(std::min(blocks_for(nf).x, ROOT_BOX_BLOCKS)), dim3(256), 0, s, d_verts, d_faces, nf, box_keys);
-    hipLaunchKernelGGL(k_kd_make_tris, blocks_for(nf), dim3(256), 0, s, d_verts, d_faces, d_face_mat, nf, tree.tris);
     hipLaunchKernelGGL(k_kd_init_root, dim3(1), dim3(1), 0, s, box_keys, cur, nf, lstate);
-    hipLaunchKernelGGL(k_kd_iota, blocks_for(nf), dim3(256), 0, s, pool_face[0], nf);
-    KCK(hipMemsetAsync(pool_owner[0], 0, (size_t)nf * sizeof(uint32_t), s));
+    // the chained sums of a launch start from zeroed words: all of them at once when the grids are known beforehand
+    size_t chain_clear = 0;
+    if (predicted)
+        for (int d = 0; d < hist_levels; d++)
+            chain_clear += chain_words(with_margin(hist_pool[d], 4096, cap_pool), 2) +
+                           chain_words(2 * (uint64_t)with_margin(hist_active[d], 256, cap_level_nodes), 4);
+    hipLaunchKernelGGL(k_kd_setup, blocks_for(nf), dim3(256), 0, s, d_verts, d_faces, d_face_mat, nf, tree.tris, pool_face[0], pool_owner[0],
+                       leaf_bits, 3 * (size_t)CODE_BLOCKS, chain, chain_clear);
 
     uint32_t n_active = 1, n_pool = nf, used_slots = 32;   // (waiting build only) the root keeps a 16-slot line of its own
     if (predicted) {
@@ -704,15 +711,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     }
     int side = 0, levels = 0;
     uint32_t grid_pool[MAX_BUILD_LEVELS], grid_active[MAX_BUILD_LEVELS];
-    // the chained sums of a launch start from zeroed words: all of them at once when the grids are known beforehand
     size_t chain_used = 0;
-    if (predicted) {
-        size_t words = 0;
-        for (int d = 0; d < hist_levels; d++)
-            words += chain_words(with_margin(hist_pool[d], 4096, cap_pool), 2) +
-                     chain_words(2 * (uint64_t)with_margin(hist_active[d], 256, cap_level_nodes), 4);
-        KCK(hipMemsetAsync(chain, 0, words * sizeof(uint32_t), s));
-    }
     EmitOut out{tree.nodes, cap_node_slots, tree.pairs, cap_pairs, leaf_heap, leaf_count, leaf_pos, leaf_child, cap_leaves, child_faces, cap_pairs, counters};
 
     for (int d = 0; predicted ? d < hist_levels : n_active > 0; d++) {   // d = depth of the active nodes, root = 0 (the reference counts from 1)
@@ -775,8 +774,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
         grid_leaves = h_counters[C_LEAVES];
         if (grid_leaves > cap_leaves) { err = "leaf list too small"; grow_leaves *= 2; return 1; }
     }
-    unsigned long long *leaf_mask = leaf_bits, *leaf_fields = leaf_bits + CODE_BLOCKS;
-    KCK(hipMemsetAsync(leaf_bits, 0, 3 * (size_t)CODE_BLOCKS * sizeof(unsigned long long), s));
+    unsigned long long *leaf_mask = leaf_bits, *leaf_fields = leaf_bits + CODE_BLOCKS;   // (cleared by k_kd_setup)
     hipLaunchKernelGGL(k_kd_leaf_mark, blocks_for(grid_leaves), dim3(256), 0, s, leaf_heap, leaf_count, counters + C_LEAVES, grid_leaves,
                        leaf_mask, leaf_fields);
     size_t tmp = scan_tmp_bytes;
