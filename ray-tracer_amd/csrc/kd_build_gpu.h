@@ -90,6 +90,7 @@ private:
     int64_t hist_faces = -1;
     uint32_t *chain = nullptr;                               // states of the sums computed inside k_kd_test / k_kd_emit
     size_t cap_chain = 0;
+    uint32_t chain_flat = 0;                                 // launches of up to this many workgroups sum in one step
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     uint32_t cap_node_slots = 0, cap_slots = 0, cap_tris = 0, cap_leaf_table = 0;

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_kd_setup(const double *verts, const uin
 // ---- exclusive sums over K flags per lane across all workgroups of a launch, in a single pass ----
 // A launch of T workgroups owns K x (T + ceil(T / 256)) words that are zero when it starts. For each of the K flags,
 // own[i] becomes CHAIN_VALID | the number of flags set in workgroup i as soon as that is known (value and mark travel in
-// one word, so no fence is needed between them). Up to CHAIN_FLAT workgroups, every workgroup simply adds up the own
+// one word, so no fence is needed between them). Up to flat_limit (CHAIN_FLAT) workgroups, every workgroup simply adds up the own
 // counts of ALL workgroups in front of it, each lane taking every 256th: T^2 / 2 loads in all, which is nothing for a few
 // thousand workgroups, and the only wait is "everybody in front has counted". Larger launches go in two steps:
 // group[g] becomes CHAIN_VALID | the number set in workgroups 256 g .. 256 g + 255, published by the last of them
@@ -159,8 +159,8 @@ __device__ __forceinline__ void chain_block_sums(uint32_t (&x)[K], uint32_t *slo
 // before one with a lower number). rank[k] = number of set flags k in front of this lane's, over the whole
 // launch; upto[k] = the same including the whole workgroup. sh: K * CHAIN_SHARED_WORDS_PER_FLAG words.
 template <int K>
-__device__ __forceinline__ void chained_ranks(uint32_t *chain, uint32_t tile, uint32_t tiles, const bool (&flag)[K], uint32_t *sh,
-                                              uint32_t *stall, uint32_t (&rank)[K], uint32_t (&upto)[K]) {
+__device__ __forceinline__ void chained_ranks(uint32_t *chain, uint32_t tile, uint32_t tiles, uint32_t flat_limit, const bool (&flag)[K],
+                                              uint32_t *sh, uint32_t *stall, uint32_t (&rank)[K], uint32_t (&upto)[K]) {
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t stride = tiles + ((tiles + 255u) >> 8);   // words per flag: own counts, then group totals
     uint32_t own[K], part[K];
@@ -170,7 +170,7 @@ __device__ __forceinline__ void chained_ranks(uint32_t *chain, uint32_t tile, ui
         for (int k = 0; k < K; k++)
             __hip_atomic_store(chain + k * stride + tile, CHAIN_VALID | own[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int k = 0; k < K; k++) part[k] = 0u;
-    if (tiles <= CHAIN_FLAT) {
+    if (tiles <= flat_limit) {
         for (uint32_t i = threadIdx.x; i < tile; i += 256u)
             for (int k = 0; k < K; k++) part[k] += chain_wait(chain + k * stride + i, stall);
     } else {
@@ -213,7 +213,7 @@ __device__ __forceinline__ uint32_t owner_of(const uint32_t *pool_owner, const u
 __global__ __launch_bounds__(256) void k_kd_test(const double *verts, const uint32_t *faces, const uint32_t *pool_face,
                                                  const uint32_t *pool_owner, const uint32_t *owner_map, const uint32_t *st,
                                                  uint32_t bound, Nodes cur, int axis, uint32_t *flags, uint2 *scanned,
-                                                 uint32_t *chain, uint32_t *stall) {
+                                                 uint32_t *chain, uint32_t flat_limit, uint32_t *stall) {
     __shared__ uint32_t sh[2 * CHAIN_SHARED_WORDS_PER_FLAG];
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     const bool in_grid = p < bound;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_kd_test(const double *verts, const uint
         flags[p] = (into[0] ? 1u : 0u) | (into[1] ? 2u : 0u);
     }
     uint32_t rank[2], upto[2];
-    chained_ranks<2>(chain, blockIdx.x, gridDim.x, into, sh, stall, rank, upto);
+    chained_ranks<2>(chain, blockIdx.x, gridDim.x, flat_limit, into, sh, stall, rank, upto);
     if (in_grid) scanned[p] = make_uint2(rank[0], rank[1]);
     if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0u) scanned[bound] = make_uint2(upto[0], upto[1]);
 }
@@ -341,7 +341,7 @@ __device__ __forceinline__ void kd_scatter(uint32_t block, const LevelIn &in, co
 // One lane per child: size of its list -> splits again / leaf / empty leaf; node records in the treelet layout, boxes of
 // the next level, leaves to a list. tile = number of the workgroup among the `tiles` that do this.
 __device__ __forceinline__ void kd_emit(uint32_t tile, uint32_t tiles, const LevelIn &in, const Nodes &cur, const Nodes &nxt, const LevelOut &o_,
-                                        const EmitOut &out, const Advance &adv, uint32_t *chain, uint32_t *sh) {
+                                        const EmitOut &out, const Advance &adv, uint32_t *chain, uint32_t flat_limit, uint32_t *sh) {
     const uint32_t *st = in.st;
     const int axis = in.axis;
     const uint32_t t = tile * 256u + threadIdx.x;
@@ -358,7 +358,7 @@ __device__ __forceinline__ void kd_emit(uint32_t tile, uint32_t tiles, const Lev
     // no atomics (those on one address are served one after the other, a microsecond per hundred waves)
     const bool adds[4] = {splits, live && !splits && n != 0u, live && c == 0u, live && !splits && n == 0u};
     uint32_t rank[4], upto[4];
-    chained_ranks<4>(chain, tile, tiles, adds, sh, &out.counters[C_STALL], rank, upto);
+    chained_ranks<4>(chain, tile, tiles, flat_limit, adds, sh, &out.counters[C_STALL], rank, upto);
     // the sizes of the next level (the sums of this one are complete in the last workgroup)
     if (tile == tiles - 1u && threadIdx.x == 0u)
         kd_advance(adv, upto[0], upto[1], upto[2] + upto[3], upto[3], st, o_.st_next, out.counters);
@@ -417,10 +417,10 @@ __device__ __forceinline__ void kd_emit(uint32_t tile, uint32_t tiles, const Lev
 // The second launch of a level. Moving the faces and making the nodes read the sums over the level's flags and nothing
 // of each other: the first workgroups move, the others make nodes.
 __global__ __launch_bounds__(256) void k_kd_next(uint32_t scatter_blocks, LevelIn in, Nodes cur, Nodes nxt, LevelOut o_, EmitOut out,
-                                                 Advance adv, uint32_t *chain) {
+                                                 Advance adv, uint32_t *chain, uint32_t flat_limit) {
     __shared__ uint32_t sh[4 * CHAIN_SHARED_WORDS_PER_FLAG];
     if (blockIdx.x < scatter_blocks) kd_scatter(blockIdx.x, in, cur, o_, out);
-    else kd_emit(blockIdx.x - scatter_blocks, gridDim.x - scatter_blocks, in, cur, nxt, o_, out, adv, chain, sh);
+    else kd_emit(blockIdx.x - scatter_blocks, gridDim.x - scatter_blocks, in, cur, nxt, o_, out, adv, chain, flat_limit, sh);
 }
 
 __device__ __forceinline__ uint32_t code_of_heap(uint32_t heap) {
@@ -655,6 +655,9 @@ int GpuKdBuilder::ensure_nodes(hipStream_t s, uint32_t slots, std::string &err) 
 // one read-back at the end tells whether every bound held. If one did not, the build is repeated the first way.
 int GpuKdBuilder::build(hipStream_t s, const double *verts, int64_t n_verts, const uint32_t *faces, const int32_t *face_mat,
                         int64_t n_faces, int max_depth, double infinity, std::string &err) {
+    // (for tests: the size from which the sums inside the kernels go in two steps, so that a small mesh can take that way)
+    if (const char *e = getenv("RT_KD_CHAIN_FLAT")) chain_flat = (uint32_t)strtoul(e, nullptr, 10);
+    else chain_flat = CHAIN_FLAT;
     if (hist_levels > 0 && hist_faces == n_faces && hist_max_depth == max_depth && !getenv("RT_KD_BUILD_SYNC")) {
         const int r = build_once(s, verts, n_verts, faces, face_mat, n_faces, max_depth, infinity, true, err);
         if (r <= 0) return r;
@@ -727,7 +730,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
         chain_used += chain_words(gp, 2) + chain_words(2 * (uint64_t)ga, 4);
         if (!predicted) KCK(hipMemsetAsync(chain_test, 0, (size_t)(chain + chain_used - chain_test) * sizeof(uint32_t), s));
         hipLaunchKernelGGL(k_kd_test, blocks_for(gp), dim3(256), 0, s, d_verts, d_faces, pool_face[side], pool_owner[side],
-                           omap, st, gp, cur, axis, flags, scanned, chain_test, counters + C_STALL);
+                           omap, st, gp, cur, axis, flags, scanned, chain_test, chain_flat, counters + C_STALL);
         const unsigned sb = blocks_for(gp).x;
         // the children of the root and of every third level below it open new 16-slot blocks
         const bool opens_block = (d % 3 == 0);
@@ -738,7 +741,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
                            out,
                            Advance{scanned + gp, gp, ga, cap_pool, cap_level_nodes,
                                    predicted ? cap_node_slots : 0xffffffffu, ((d + 1) % 3 == 0) ? 1 : 0},
-                           chain_emit);
+                           chain_emit, chain_flat);
         KCK(hipGetLastError());
         levels = d + 1;
         if (!predicted) {

@@ -36,6 +36,42 @@ def test_device_builder_bit_exact_against_reference(ply, gold):
     rt.close()
 
 
+def test_device_builder_sums_in_two_steps(monkeypatch):
+    """The exclusive sums inside the builder's kernels go in two steps (groups of 256 workgroups) for launches of more
+    than 2048 workgroups, which none of the test meshes reaches. RT_KD_CHAIN_FLAT lowers that size: with 0 every launch
+    goes the two-step way, and the full bunny (levels of up to 1065 workgroups, five groups) must still give the
+    reference's arrays, on the first build (level by level) and on the second (all levels queued at once)."""
+    monkeypatch.setenv("RT_KD_CHAIN_FLAT", "0")
+    test_device_builder_bit_exact_against_reference("bun_zipper.ply", "k8_full_640x480")
+    test_device_builder_random_meshes_match_oracle()
+
+
+def test_device_builder_large_mesh_equals_host_builder():
+    """A height field of 500 000 faces: levels of more than 2048 workgroups (the sums inside the kernels then go in two
+    steps without any test hook) and lists an order of magnitude longer than the bunny's. The oracle would need minutes
+    for it; the check is the threaded host builder, which the CPU tests pin to the reference and to the oracle."""
+    n = 501
+    gx, gy = np.meshgrid(np.arange(n, dtype=np.float64), np.arange(n, dtype=np.float64), indexing="ij")
+    gz = 12.0 * np.sin(gx * 0.045) * np.cos(gy * 0.031) + 3.0 * np.sin(gx * 0.21 + gy * 0.17)
+    v = np.stack([gx * 0.4 - 100.0, gz, gy * 0.4 - 100.0], axis=-1).reshape(-1, 3)
+    idx = (np.arange(n - 1)[:, None] * n + np.arange(n - 1)[None, :]).reshape(-1)
+    f = np.concatenate([np.stack([idx, idx + 1, idx + n], axis=1), np.stack([idx + 1, idx + n + 1, idx + n], axis=1)]).astype(np.uint32)
+    assert len(f) == 500000
+    fm = np.zeros((len(f), 2), np.uint32)
+    rt = abi.RayTracerHIP(abi.default_config(64, 48))
+    rt.setMesh(v, f, fm)
+    rt.buildKdTree(on_device=False)
+    hp, hl, hb = rt.exportKdTree()
+    for _ in range(2):   # level by level, then all levels queued at once
+        rt.setMesh(v, f, fm)
+        rt.buildKdTree(on_device=True)
+        pairs, leaves, box = rt.exportKdTree()
+        assert np.array_equal(hb, box)
+        assert np.array_equal(hl, leaves)
+        assert np.array_equal(hp, pairs)
+    rt.close()
+
+
 def test_device_builder_random_meshes_match_oracle():
     rng = np.random.default_rng(11)
     rt = abi.RayTracerHIP(abi.default_config(64, 48))
