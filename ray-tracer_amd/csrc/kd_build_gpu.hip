@@ -126,10 +126,10 @@ __global__ __launch_bounds__(256) void k_kd_setup(const double *verts, const uin
 // lane) and the totals of the groups in front of that. Either way there is no chain of dependent hand-overs: a value
 // takes about as long from one workgroup to another as a small kernel takes in all.
 // A workgroup only ever waits for workgroups with a lower index: those are dispatched before it, so they are running or
-// done. A wait that lasts longer than any launch could (a fraction of a second) gives up and says so in *stall: the
+// done. A wait that lasts longer than any launch could (seconds) gives up and says so in *stall: the
 // build is then reported as failed, and no wave ever waits without end.
 constexpr uint32_t CHAIN_VALID = 0x80000000u;
-constexpr uint32_t CHAIN_POLL_LIMIT = 1u << 18;
+constexpr uint32_t CHAIN_POLL_LIMIT = 1u << 22;   // several seconds: kernels of other streams may hold back a workgroup for a while
 constexpr uint32_t CHAIN_FLAT = 2048;
 constexpr int CHAIN_SHARED_WORDS_PER_FLAG = 12;
 
