@@ -118,16 +118,16 @@ __global__ __launch_bounds__(256) void k_kd_setup(const double *verts, const uin
 // ---- exclusive sums over K flags per lane across all workgroups of a launch, in a single pass ----
 // A launch of T workgroups owns K x (T + ceil(T / 256)) words that are zero when it starts. For each of the K flags,
 // own[i] becomes CHAIN_VALID | the number of flags set in workgroup i as soon as that is known (value and mark travel in
-// one word, so no fence is needed between them). Up to flat_limit (CHAIN_FLAT) workgroups, every workgroup simply adds up the own
-// counts of ALL workgroups in front of it, each lane taking every 256th: T^2 / 2 loads in all, which is nothing for a few
-// thousand workgroups, and the only wait is "everybody in front has counted". Larger launches go in two steps:
+// one word, so no fence is needed between them). Up to flat_limit (CHAIN_FLAT) workgroups, every workgroup simply adds
+// up the own counts of ALL workgroups in front of it, each lane taking every 256th: T^2 / 2 loads in all, which is nothing
+// for a few thousand workgroups, and the only wait is "everybody in front has counted". Larger launches go in two steps:
 // group[g] becomes CHAIN_VALID | the number set in workgroups 256 g .. 256 g + 255, published by the last of them
 // before it looks at the groups in front, and a workgroup adds the own counts in front of it in its group (one per
 // lane) and the totals of the groups in front of that. Either way there is no chain of dependent hand-overs: a value
 // takes about as long from one workgroup to another as a small kernel takes in all.
 // A workgroup only ever waits for workgroups with a lower index: those are dispatched before it, so they are running or
-// done. A wait that lasts longer than any launch could (seconds) gives up and says so in *stall: the
-// build is then reported as failed, and no wave ever waits without end.
+// done. A wait that lasts longer than any launch could (seconds) gives up and says so in *stall: the build is then
+// reported as failed, and no wave ever waits without end.
 constexpr uint32_t CHAIN_VALID = 0x80000000u;
 constexpr uint32_t CHAIN_POLL_LIMIT = 1u << 22;   // several seconds: kernels of other streams may hold back a workgroup for a while
 constexpr uint32_t CHAIN_FLAT = 2048;
