@@ -44,6 +44,7 @@ def test_device_builder_sums_in_two_steps(monkeypatch):
     monkeypatch.setenv("RT_KD_CHAIN_FLAT", "0")
     test_device_builder_bit_exact_against_reference("bun_zipper.ply", "k8_full_640x480")
     test_device_builder_random_meshes_match_oracle()
+    test_device_builder_large_mesh_equals_host_builder()
 
 
 def test_device_builder_large_mesh_equals_host_builder():
