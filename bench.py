@@ -240,16 +240,25 @@ def main():
 
     # the same frame with the canvas copied to a host buffer (what a caller without device memory pays);
     # reported beside the metric, never as the metric
-    pcie_ms = None
+    pcie_ms = pcie_pinned_ms = None
     if world == 1:
         n_pcie = min(K, 5)
         sync_frame = multi_gpu.FrameJob(rt, comm)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(n_pcie):
+        pageable = np.zeros((args.height, args.width, 4), np.uint8)
+        pinned = torch.empty((args.height, args.width, 4), dtype=torch.uint8).pin_memory().numpy()
+        for dst in (pageable, pinned):
             sync_frame.step()
-            rt.readRGBA8()
-        pcie_ms = (time.perf_counter() - t1) / n_pcie * 1e3
+            rt.readRGBA8(dst)            # (touches the pages once)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_pcie):
+                sync_frame.step()
+                rt.readRGBA8(dst)
+            ms = (time.perf_counter() - t1) / n_pcie * 1e3
+            if dst is pageable:
+                pcie_ms = ms
+            else:
+                pcie_pinned_ms = ms
 
     if rank != 0:
         comm.close()
@@ -274,7 +283,8 @@ def main():
         },
         "mshadow_rays_per_s": shadow / (dt / K) / 1e6,
         "pcie_inclusive": None if pcie_ms is None else {"ms_per_step": pcie_ms, "value": rays / (pcie_ms * 1e-3) / 1e6,
-                                                        "note": "step + rt_read_rgba8 of the 3840x2160 RGBA8 target into pageable host memory"},
+                                                        "ms_per_step_pinned": pcie_pinned_ms, "value_pinned": rays / (pcie_pinned_ms * 1e-3) / 1e6,
+                                                        "note": "one frame at a time + rt_read_rgba8 of the %dx%d RGBA8 target into the caller's host buffer: pageable memory, and (_pinned) page-locked memory" % (args.width, args.height)},
         "trace_only_ms": trace_ms, "composite_ms": comp_ms, "tone_ms": tone_ms,
         "frames_in_flight": n_ctx, "frame_job": "pipelined (stream-ordered, device-resident exchange)" if pipelined else "host-synchronised",
         "frames_retraced": getattr(frame, "redone", 0),

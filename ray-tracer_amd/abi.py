@@ -270,8 +270,13 @@ class RayTracerHIP:
         self._ck(self.L.rt_read_float(self.ctx, out.ctypes.data), "rt_read_float")
         return out
 
-    def readRGBA8(self):
-        out = np.zeros((self.H, self.W, 4), np.uint8)
+    def readRGBA8(self, out=None):
+        """The canvas as (H, W, 4) bytes; `out`: a caller's buffer of that many bytes to fill instead of a new array
+        (anything with the array interface, e.g. a pinned torch tensor's .numpy())."""
+        if out is None:
+            out = np.zeros((self.H, self.W, 4), np.uint8)
+        elif out.nbytes != self.H * self.W * 4 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("readRGBA8: out must be a contiguous buffer of H*W*4 bytes")
         self._ck(self.L.rt_read_rgba8(self.ctx, out.ctypes.data), "rt_read_rgba8")
         return out
 
