@@ -646,7 +646,7 @@ int GpuKdBuilder::ensure_nodes(hipStream_t s, uint32_t slots, std::string &err) 
 }
 
 // The lists are sized from the face count; a mesh whose faces spread over many more cells than usual asks for more:
-// the list that ran out is enlarged and the build starts over.
+// the list that ran out is made four times as long and the build starts over.
 //
 // Two ways through a build. The first build of a mesh waits for the sizes of every level (one small read-back per
 // level), because nothing is known about the tree. It leaves the sizes behind, and the next build of a mesh with the
@@ -663,7 +663,7 @@ int GpuKdBuilder::build(hipStream_t s, const double *verts, int64_t n_verts, con
         if (r <= 0) return r;
         predicted_misses++;
     }
-    for (int attempt = 0; attempt < 12; attempt++) {
+    for (int attempt = 0; attempt < 24; attempt++) {   // (three lists, each up to 2^20 times its first size in steps of 4)
         const int r = build_once(s, verts, n_verts, faces, face_mat, n_faces, max_depth, infinity, false, err);
         if (r <= 0) return r;
     }
@@ -748,8 +748,8 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
             KCK(hipMemcpyAsync(h_lstate + (size_t)(d + 1) * ST_WORDS, st + ST_WORDS, ST_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             KCK(hipStreamSynchronize(s));
             const uint32_t *hn = h_lstate + (size_t)(d + 1) * ST_WORDS;
-            if (hn[ST_OVER] & 1u) { err = "face pool too small"; grow_pool *= 2; return 1; }
-            if (hn[ST_OVER] & 2u) { err = "level node arrays too small"; grow_nodes *= 2; return 1; }
+            if (hn[ST_OVER] & 1u) { err = "face pool too small"; grow_pool = std::min(grow_pool * 4, 1 << 20); return 1; }
+            if (hn[ST_OVER] & 2u) { err = "level node arrays too small"; grow_nodes = std::min(grow_nodes * 4, 1 << 20); return 1; }
             if (hn[ST_OVER] & 8u) { err = "device k-d build: node array too large"; return -1; }
             hist_pool[d] = n_pool; hist_active[d] = n_active;
             n_pool = hn[ST_POOL];
@@ -775,7 +775,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
         KCK(hipMemcpyAsync(h_counters, counters, C_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         KCK(hipStreamSynchronize(s));
         grid_leaves = h_counters[C_LEAVES];
-        if (grid_leaves > cap_leaves) { err = "leaf list too small"; grow_leaves *= 2; return 1; }
+        if (grid_leaves > cap_leaves) { err = "leaf list too small"; grow_leaves = std::min(grow_leaves * 4, 1 << 20); return 1; }
     }
     unsigned long long *leaf_mask = leaf_bits, *leaf_fields = leaf_bits + CODE_BLOCKS;   // (cleared by k_kd_setup)
     hipLaunchKernelGGL(k_kd_leaf_mark, blocks_for(grid_leaves), dim3(256), 0, s, leaf_heap, leaf_count, counters + C_LEAVES, grid_leaves,
@@ -804,11 +804,11 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
         }
         if (!ok) { err = "a predicted size did not hold"; return 1; }
     }
-    if (n_leaves > cap_leaves) { err = "leaf list too small"; grow_leaves *= 2; return 1; }
+    if (n_leaves > cap_leaves) { err = "leaf list too small"; grow_leaves = std::min(grow_leaves * 4, 1 << 20); return 1; }
     const unsigned long long total = *h_total;
     if ((uint32_t)(total >> 32) != n_leaves) { err = "device k-d build: two leaves share a path code"; return -1; }
     // (the leaves' records follow those of the inner nodes and empty leaves)
-    if ((uint64_t)h_counters[C_PAIRS] + n_leaves > cap_pairs) { err = "node list too small"; grow_leaves *= 2; return 1; }
+    if ((uint64_t)h_counters[C_PAIRS] + n_leaves > cap_pairs) { err = "node list too small"; grow_leaves = std::min(grow_leaves * 4, 1 << 20); return 1; }
     for (int k = 0; k < 6; k++) tree.root_box[k] = key_value(hk[k]);
     tree.n_internal = 0;
     int real_levels = 0;   // a tree that got shallower leaves the last predicted levels without nodes

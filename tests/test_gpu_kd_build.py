@@ -73,6 +73,32 @@ def test_device_builder_large_mesh_equals_host_builder():
     rt.close()
 
 
+def test_device_builder_lists_grow_for_a_flat_mesh():
+    """120 faces in one plane: the root box has no extent on one axis, a third of the levels separate nothing, and the
+    tree grows to millions of nodes. The builder's lists, sized from the face count, run out several times over (faces
+    per level, nodes per level, leaves); each time the list that ran out is made longer and the build starts again. The
+    check is the host builder (the oracle would need minutes)."""
+    rng = np.random.default_rng(21)
+    n_faces = 120
+    v = rng.uniform(-50, 50, size=(n_faces * 2, 3))
+    f = rng.integers(0, len(v), size=(n_faces, 3)).astype(np.uint32)
+    v[f[:, 1]] = v[f[:, 0]] + rng.normal(0, 2.0, size=(n_faces, 3))
+    v[f[:, 2]] = v[f[:, 0]] + rng.normal(0, 2.0, size=(n_faces, 3))
+    v[:, 1] = 1.5
+    fm = np.zeros((n_faces, 2), np.uint32)
+    rt = abi.RayTracerHIP(abi.default_config(64, 48))
+    rt.setMesh(v, f, fm)
+    rt.buildKdTree(on_device=False)
+    hp, hl, hb = rt.exportKdTree()
+    assert len(hp) > 1000000
+    for _ in range(2):
+        rt.setMesh(v, f, fm)
+        rt.buildKdTree(on_device=True)
+        pairs, leaves, box = rt.exportKdTree()
+        assert np.array_equal(hb, box) and np.array_equal(hl, leaves) and np.array_equal(hp, pairs)
+    rt.close()
+
+
 def test_device_builder_random_meshes_match_oracle():
     rng = np.random.default_rng(11)
     rt = abi.RayTracerHIP(abi.default_config(64, 48))
