@@ -298,8 +298,12 @@ def test_sharded_render_assembles_to_the_full_frame(n_shards):
     """n shard contexts on one GPU (n = 3 does not divide the tile count; the frame is ragged on both edges): tiles
     interleave, partial tone sums add up, the assembled render target equals the unsharded one byte for byte - and so
     does the canvas when every shard tone-maps its own tiles (rt_present_shard) and the root only scatters them."""
+    sharded_render_check(n_shards, 203, 117, 3)
+
+
+def sharded_render_check(n_shards, width, height, depth):
     import ctypes as C
-    flat = make_flat("bun_zipper_res4.ply", 203, 117, depth=3)
+    flat = make_flat("bun_zipper_res4.ply", width, height, depth=depth)
     full = render_hip(flat)
     want = full.readRGBA8()
     ws, wn = full.tonePartial()
@@ -336,7 +340,7 @@ def test_sharded_render_assembles_to_the_full_frame(n_shards):
         bufs.append(fetch(L.rt_device_shard_rgba8, rt))
         parts.append(rt)
     flat.cfg.shard_index, flat.cfg.shard_count = 0, 1
-    assert cnt == wn == 203 * 117
+    assert cnt == wn == width * height
     assert abs(sums - ws) <= 1e-12 * abs(ws)
     root = abi.RayTracerHIP(flat.cfg)
     dptr, stride = upload(bufs)
