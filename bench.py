@@ -128,6 +128,11 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))     # one process per GPU, started from here
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    # stdout carries the JSON line and nothing else: whatever native libraries print on descriptor 1 (gloo announces
+    # its connections there) goes to stderr from here on
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.spawn_check:
         import torch
         import torch.distributed as dist
@@ -135,7 +140,8 @@ def main():
         t = torch.tensor([rank + 1], dtype=torch.int64)
         dist.all_reduce(t)
         if rank == 0:
-            print(json.dumps({"n_gpus": world, "rank_sum": int(t[0])}))
+            json_out.write(json.dumps({"n_gpus": world, "rank_sum": int(t[0])}) + "\n")
+            json_out.flush()
         dist.destroy_process_group()
         return
 
@@ -388,7 +394,8 @@ def main():
         }
         out["kernels"] = table
         out["algorithmic_frame"] = {k: v * scale * tile_world for k, v in cn.algorithmic(None).items()}
-    print(json.dumps(out))
+    json_out.write(json.dumps(out) + "\n")
+    json_out.flush()
     comm.close()
 
 
