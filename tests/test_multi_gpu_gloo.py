@@ -213,8 +213,8 @@ def _run_bench(args, timeout=600):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(_ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
+    lines = p.stdout.splitlines()   # the JSON line and nothing else (gloo's connection notices belong on stderr)
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
     return json.loads(lines[0])
 
 
