@@ -56,7 +56,7 @@ typedef struct rt_config {
     float   plane_rect_epsilon;  /* PLANE_RECT_EPSILON = 0.095 */
     float   triangle_epsilon;    /* TRIANGLE_EPSILON = 1e-4 */
     /* multi-GPU sharding of the image: this context renders the 8x8-pixel tiles whose
-     * index (row-major over tiles) is congruent to shard_index modulo shard_count.
+     * index (blocks of 16x16 tiles row by row, Z-order inside a block) is congruent to shard_index modulo shard_count.
      * shard_count <= 1 renders the whole frame. No counterpart in the reference. */
     int32_t shard_index;
     int32_t shard_count;
@@ -168,6 +168,15 @@ int rt_kdtree_counts(rt_ctx *ctx, int64_t *n_nodes, int64_t *n_leaves);
  * `leaves` receives n_leaves*4 face indices = kdLeavesData (:2504-2508); root_box = root.min, root.max */
 int rt_export_kdtree_reference(rt_ctx *ctx, uint32_t *nodes, int32_t *leaves, double root_box[6]);
 
+/* The tree's overhang, as the closest-hit walk uses it to skip subtrees that cannot hold the nearest hit: out[0..2] =
+ * the largest amount by which a face listed by a leaf reaches below that leaf's cell on x, y, z, out[3..5] = above it,
+ * measured on the float32 vertices and float32 cells the shader works with (js/8-kd_tree.js:873-885, :2462-2464), plus
+ * a safety margin of 1/256 of the root box's largest side. A subtree entered across a split plane of axis a at ray
+ * distance t holds no hit nearer than t - out[a] / |d[a]|; the reference visits such subtrees (js/8-kd_tree.js:862-962
+ * has no early exit) and finds nothing nearer there, so skipping them leaves every pixel as it is. No counterpart
+ * in the reference. */
+int rt_kdtree_overhang(rt_ctx *ctx, float out[6]);
+
 /* ---- frame: replaces the tracer draw call (js/8-kd_tree.js:2550-2555) -------------------- */
 int rt_trace(rt_ctx *ctx);
 /* The same frame in two halves, for callers that overlap work with the trace. No counterpart in the reference
@@ -247,7 +256,9 @@ int rt_assemble_shards_canvas(rt_ctx *ctx, const void *gathered, size_t stride_b
 /* The HIP stream (hipStream_t) on which this context queues its work. Work a caller queues on it - a collective, a
  * copy - is ordered with the library's kernels without any host synchronisation. No counterpart in the reference. */
 int rt_stream(rt_ctx *ctx, void **stream);
-/* Tuning knobs by name. "walk_waves_per_cu" (1..32, default 24): persistent waves per compute unit of the k-d walk;
+/* Tuning knobs by name. "prune" (0 / 1, default 1): the closest-hit walk skips subtrees that cannot hold the nearest
+ * hit (see rt_kdtree_overhang); 0 visits every cell of the root interval like the reference - the frames are identical.
+ * "walk_waves_per_cu" (1..32, default 24): persistent waves per compute unit of the k-d walk;
  * two contexts that trace concurrently on one GPU fit side by side at 12. "stage_timing" (0 / 1, default 1): HIP events
  * around every stage kernel, which fill rt_stats.level_stage_ms / stage_ms / level_kernel_ms; without them those
  * fields are zero and a frame is about thirty queue entries shorter. "first_level_rays" (0 = default): capacity of the

@@ -506,6 +506,13 @@ static f3 illuminate(const oracle_scene *sc, const HitInfo *h, f3 rd, float *ref
     return add3(F3(0, 0, 0), add3(add3(ambient, specular), diffuse));
 }
 
+/* Observer of every closest-hit k-d search, for counting tools that include this file (tools/prune_probe): called after
+ * the traversal with the ray, the distance the search started from (the analytic winner's or INFINITY) and the result. */
+typedef void (*oracle_closest_hook_fn)(const oracle_scene *sc, const float *ro3, const float *rd3, float t_seed, float t_best,
+                                       int face_best, int level);
+static oracle_closest_hook_fn g_closest_hook;
+void oracle_set_closest_hook(oracle_closest_hook_fn f) { g_closest_hook = f; }
+
 /* The closest-hit search of one ray-tree node (js/8-kd_tree.js:846-990): analytic primitives in scene order, then the
  * mesh. Fills h (hit flag) and best; *prim_hit = index of the winning analytic primitive or -1. */
 static void findClosest(const oracle_scene *sc, f3 ro, f3 rd, HitInfo *hp, Closest *bp, int *prim_hit_p, oracle_counters *cn, int level) {
@@ -528,7 +535,12 @@ static void findClosest(const oracle_scene *sc, f3 ro, f3 rd, HitInfo *hp, Close
         }
         if (sc->cfg.render_triangles) {
             if (sc->cfg.use_kd_tree) {
+                const float t_seed = best.tMin;
                 kdTraverse(sc, ro, rd, &h, 1, &best, cn, level);
+                if (g_closest_hook) {
+                    const float o3[3] = { ro.x, ro.y, ro.z }, d3[3] = { rd.x, rd.y, rd.z };
+                    g_closest_hook(sc, o3, d3, t_seed, best.tMin, best.face, level);
+                }
             } else {
                 for (int32_t i = 0; i < sc->n_faces; i++) {
                     f3 tv[3]; fetchTri(sc, i, tv);

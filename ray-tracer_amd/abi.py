@@ -140,6 +140,7 @@ def lib():
         L.rt_build_kdtree_device.argtypes = [vp]
         L.rt_kdtree_counts.argtypes = [vp, i64p, i64p]
         L.rt_export_kdtree_reference.argtypes = [vp, vp, vp, vp]
+        L.rt_kdtree_overhang.argtypes = [vp, vp]
         L.rt_trace.argtypes = [vp]
         L.rt_trace_begin.argtypes = [vp]
         L.rt_trace_end.argtypes = [vp]
@@ -250,6 +251,13 @@ class RayTracerHIP:
         self._ck(self.L.rt_export_kdtree_reference(self.ctx, pairs.ctypes.data, leaves.ctypes.data, box.ctypes.data),
                  "rt_export_kdtree_reference")
         return pairs, leaves, box
+
+    def kdOverhang(self):
+        """How far listed faces reach below (x, y, z) / above (x, y, z) the cells of the leaves that list them, with the
+        safety margin the walk prunes with."""
+        out = np.zeros(6, np.float32)
+        self._ck(self.L.rt_kdtree_overhang(self.ctx, out.ctypes.data), "rt_kdtree_overhang")
+        return out
 
     def trace(self):
         self._ck(self.L.rt_trace(self.ctx), "rt_trace")

@@ -40,6 +40,20 @@ struct KdTreeHost {
 void build_kdtree(const double *verts, int64_t n_verts, const uint32_t *faces, int64_t n_faces, int max_depth,
                   double infinity, int n_threads, KdTreeHost &out);
 
+// Overhang of a tree as the walk uses it (SceneDev::over_lo / over_hi in rt_device.h). raw = the largest amounts by which
+// the float32 vertices of a listed face reach below (xyz) / above (xyz) the float32 cell of a leaf that lists it; the
+// margin for the rounding of the triangle test is 1/256 of the float32 root box's largest side, and the result is
+// rounded up (the subtractions behind raw can be half an ulp short).
+inline void kd_overhang_with_margin(const float raw[6], const double root_box[6], float out[6]) {
+    float side = 0.0f;
+    for (int c = 0; c < 3; c++) {
+        const float s = (float)root_box[3 + c] - (float)root_box[c];
+        if (s > side) side = s;
+    }
+    const float slack = side * (1.0f / 256.0f);
+    for (int c = 0; c < 6; c++) out[c] = (raw[c] + slack) * 1.000001f;
+}
+
 // canonical reference arrays: (heapIndex, metadata) pairs ascending by heap index
 void export_reference(const KdTreeHost &t, uint32_t *pairs);
 

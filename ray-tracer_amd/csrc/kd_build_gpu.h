@@ -28,6 +28,7 @@ struct GpuKdTree {
     int32_t *leaves = nullptr;      // reference leaf table: n_leaves x 4 face indices, -1 = unused
     uint32_t n_leaves = 0;
     double root_box[6] = {0, 0, 0, 0, 0, 0};
+    float over[6] = {0, 0, 0, 0, 0, 0};   // SceneDev::over_lo / over_hi
     int64_t n_internal = 0, n_leaf = 0, n_empty = 0;
     int depth = 0;
     double build_ms = 0;            // device time of the last build
@@ -78,6 +79,7 @@ private:
     unsigned long long *leaf_bits = nullptr;                 // per block of 64 path codes: mask of the leaves, then their face counts
     unsigned long long *block_scan = nullptr;                // (leaves, faces) in front of each block
     uint32_t *leaf_heap = nullptr, *leaf_count = nullptr, *leaf_pos = nullptr, *leaf_child = nullptr;
+    float *leaf_box = nullptr;                               // 6 * cap_leaves: float32 cell of every leaf with faces
     uint32_t *child_faces = nullptr;                         // 4 * cap_pairs: the first faces of every child's list
     uint32_t cap_leaves = 0, cap_pairs = 0;
     uint32_t *counters = nullptr;                            // device: leaves, pairs, empties, root box keys

@@ -285,6 +285,7 @@ struct EmitOut {
     uint2 *pairs;
     uint32_t cap_pairs;
     uint32_t *leaf_heap, *leaf_count, *leaf_pos, *leaf_child;
+    float *leaf_box;         // the shader's float32 cell of every leaf with faces: lo xyz, hi xyz
     uint32_t cap_leaves;
     uint32_t *child_faces;   // the first four faces of every child's list, by the child's number over the whole build
     uint32_t cap_children;
@@ -412,6 +413,10 @@ __device__ __forceinline__ void kd_emit(uint32_t tile, uint32_t tiles, const Lev
     out.leaf_count[li] = n < 4u ? n : 4u;
     out.leaf_pos[li] = cpos;
     out.leaf_child[li] = st[ST_CHILDREN] + t;
+    for (int k = 0; k < 3; k++) {
+        out.leaf_box[6 * (size_t)li + k] = (k == axis && c == 1u) ? split : cur.flo[3 * (size_t)o + k];
+        out.leaf_box[6 * (size_t)li + 3 + k] = (k == axis && c == 0u) ? split : cur.fhi[3 * (size_t)o + k];
+    }
 }
 
 // The second launch of a level. Moving the faces and making the nodes read the sums over the level's flags and nothing
@@ -468,9 +473,42 @@ __global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap,
                                                       const unsigned long long *mask, const unsigned long long *fields,
                                                       const unsigned long long *block_scan, const TriDev *tris, uint32_t n_tris, KdNodeDev *nodes,
                                                       uint32_t node_cap, TriGeo *lgeo, TriTag *ltag, uint32_t cap_slots, uint32_t *path_slot,
-                                                      int32_t *leaves, uint2 *pairs, uint32_t cap_pairs, uint32_t *counters) {
+                                                      int32_t *leaves, uint2 *pairs, uint32_t cap_pairs, uint32_t *counters,
+                                                      const double *verts, const uint32_t *faces, const float *leaf_box, uint32_t *over_bits) {
+    __shared__ uint32_t s_over[6][4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= min(*n_leaves, bound)) return;
+    const bool live = i < min(*n_leaves, bound);
+    // Overhang of the tree (SceneDev::over_lo / over_hi): how far the float32 vertices of a listed face reach below /
+    // above the leaf's float32 cell. Non-negative floats order like their bits: one atomic maximum per workgroup and
+    // component (atomics on one address are served one after the other).
+    float over[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (live) {
+        const uint32_t cnt = leaf_count[i], child = leaf_child[i];
+        for (uint32_t k = 0; k < cnt && child < cap_children; k++) {
+            const uint32_t f = child_faces[4 * (size_t)child + k];
+            if (f >= n_tris) continue;
+            for (int j = 0; j < 3; j++) {
+                const double *v = verts + 3 * (size_t)faces[3 * (size_t)f + j];
+                for (int c = 0; c < 3; c++) {
+                    const float x = (float)v[c];
+                    over[c] = fmaxf(over[c], leaf_box[6 * (size_t)i + c] - x);
+                    over[3 + c] = fmaxf(over[3 + c], x - leaf_box[6 * (size_t)i + 3 + c]);
+                }
+            }
+        }
+    }
+    for (int c = 0; c < 6; c++) {
+        float v = over[c];
+        for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+        if ((threadIdx.x & 63u) == 0u) s_over[c][threadIdx.x >> 6] = __float_as_uint(v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6u) {
+        const uint32_t *w = s_over[threadIdx.x];
+        const uint32_t m = max(max(w[0], w[1]), max(w[2], w[3]));
+        if (m) atomicMax(&over_bits[threadIdx.x], m);
+    }
+    if (!live) return;
     const uint32_t heap = leaf_heap[i], code = code_of_heap(heap), cnt = leaf_count[i], child = leaf_child[i];
     const uint32_t key = ~code & (CODES - 1u), b = key >> 6, bit = key & 63u;
     const unsigned long long before = block_scan[b];
@@ -543,7 +581,7 @@ GpuKdBuilder::~GpuKdBuilder() { release(); }
 void GpuKdBuilder::release() {
     void *ptrs[] = {d_verts, d_faces, d_face_mat, pool_face[0], pool_face[1], pool_owner[0], pool_owner[1], flags, scanned,
                     owner_map[0], owner_map[1], leaf_bits, block_scan, leaf_heap, leaf_count,
-                    leaf_pos, leaf_child, child_faces, counters, lstate, scan_tmp, chain, tree.nodes, tree.tris, tree.lgeo, tree.ltag, tree.path_slot, tree.pairs,
+                    leaf_pos, leaf_child, leaf_box, child_faces, counters, lstate, scan_tmp, chain, tree.nodes, tree.tris, tree.lgeo, tree.ltag, tree.path_slot, tree.pairs,
                     tree.leaves};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -561,8 +599,8 @@ void GpuKdBuilder::release() {
 int GpuKdBuilder::reserve(int64_t n_verts, int64_t n_faces, std::string &err) {
     if (!ev0) { KCK(hipEventCreate(&ev0)); KCK(hipEventCreate(&ev1)); }
     if (!counters) {
-        KCK(hipMalloc((void **)&counters, (C_WORDS + 12) * sizeof(uint32_t)));   // counters, then six 64-bit box keys
-        KCK(hipHostMalloc((void **)&h_counters, (C_WORDS + 12) * sizeof(uint32_t)));
+        KCK(hipMalloc((void **)&counters, (C_WORDS + 18) * sizeof(uint32_t)));   // counters, six 64-bit box keys, six overhang maxima (float bits)
+        KCK(hipHostMalloc((void **)&h_counters, (C_WORDS + 18) * sizeof(uint32_t)));
         KCK(hipMalloc((void **)&lstate, (size_t)MAX_BUILD_LEVELS * ST_WORDS * sizeof(uint32_t)));
         KCK(hipHostMalloc((void **)&h_lstate, (size_t)MAX_BUILD_LEVELS * ST_WORDS * sizeof(uint32_t)));
         KCK(hipHostMalloc((void **)&h_total, sizeof(unsigned long long)));
@@ -595,7 +633,7 @@ int GpuKdBuilder::reserve(int64_t n_verts, int64_t n_faces, std::string &err) {
     const uint32_t want_leaves = (uint32_t)std::min<int64_t>(std::max<int64_t>(n_faces * 8, 1 << 16) * (int64_t)grow_leaves, 1 << 27);
     if (want_leaves > cap_leaves) {
         if (grow(leaf_heap, want_leaves, err) || grow(leaf_count, want_leaves, err) || grow(leaf_pos, want_leaves, err) ||
-            grow(leaf_child, want_leaves, err) || grow(tree.leaves, 4 * (size_t)want_leaves, err) ||
+            grow(leaf_child, want_leaves, err) || grow(leaf_box, 6 * (size_t)want_leaves, err) || grow(tree.leaves, 4 * (size_t)want_leaves, err) ||
             grow(tree.lgeo, 4 * (size_t)want_leaves, err) || grow(tree.ltag, 4 * (size_t)want_leaves, err))
             return -1;
         cap_leaves = want_leaves;
@@ -691,9 +729,9 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     unsigned long long *hk = (unsigned long long *)(h_counters + C_WORDS);
     Nodes cur{lv[0].blo, lv[0].bhi, lv[0].flo, lv[0].fhi, lv[0].heap, lv[0].start, lv[0].count, lv[0].pos};
     Nodes nxt{lv[1].blo, lv[1].bhi, lv[1].flo, lv[1].fhi, lv[1].heap, lv[1].start, lv[1].count, lv[1].pos};
-    memset(h_counters, 0, (C_WORDS + 12) * sizeof(uint32_t));
+    memset(h_counters, 0, (C_WORDS + 18) * sizeof(uint32_t));
     for (int k = 0; k < 3; k++) { hk[k] = host_order_key(infinity); hk[3 + k] = host_order_key(-infinity); }
-    KCK(hipMemcpyAsync(counters, h_counters, (C_WORDS + 12) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    KCK(hipMemcpyAsync(counters, h_counters, (C_WORDS + 18) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_kd_root_box, dim3(std::min(blocks_for(nf).x, ROOT_BOX_BLOCKS)), dim3(256), 0, s, d_verts, d_faces, nf, box_keys);
     hipLaunchKernelGGL(k_kd_init_root, dim3(1), dim3(1), 0, s, box_keys, cur, nf, lstate);
     // the chained sums of a launch start from zeroed words: all of them at once when the grids are known beforehand
@@ -715,7 +753,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     int side = 0, levels = 0;
     uint32_t grid_pool[MAX_BUILD_LEVELS], grid_active[MAX_BUILD_LEVELS];
     size_t chain_used = 0;
-    EmitOut out{tree.nodes, cap_node_slots, tree.pairs, cap_pairs, leaf_heap, leaf_count, leaf_pos, leaf_child, cap_leaves, child_faces, cap_pairs, counters};
+    EmitOut out{tree.nodes, cap_node_slots, tree.pairs, cap_pairs, leaf_heap, leaf_count, leaf_pos, leaf_child, leaf_box, cap_leaves, child_faces, cap_pairs, counters};
 
     for (int d = 0; predicted ? d < hist_levels : n_active > 0; d++) {   // d = depth of the active nodes, root = 0 (the reference counts from 1)
         if (d >= MAX_BUILD_LEVELS - 1) { err = "device k-d build: too many levels"; return -1; }
@@ -785,10 +823,10 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     KCK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tmp, totals, block_scan, (int)(CODE_BLOCKS + 1), s));
     hipLaunchKernelGGL(k_kd_leaf_emit, blocks_for(grid_leaves), dim3(256), 0, s, leaf_heap, leaf_count, leaf_pos, leaf_child, child_faces, cap_pairs,
                        counters + C_LEAVES, grid_leaves, leaf_mask, leaf_fields, block_scan, tree.tris, nf, tree.nodes, cap_node_slots, tree.lgeo, tree.ltag, cap_slots,
-                       tree.path_slot, tree.leaves, tree.pairs, cap_pairs, counters);
+                       tree.path_slot, tree.leaves, tree.pairs, cap_pairs, counters, d_verts, d_faces, leaf_box, counters + C_WORDS + 12);
     KCK(hipGetLastError());
     KCK(hipMemcpyAsync(h_total, block_scan + CODE_BLOCKS, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    KCK(hipMemcpyAsync(h_counters, counters, (C_WORDS + 12) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    KCK(hipMemcpyAsync(h_counters, counters, (C_WORDS + 18) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     KCK(hipMemcpyAsync(h_lstate, lstate, (size_t)(levels + 1) * ST_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     KCK(hipEventRecord(ev1, s));
     KCK(hipStreamSynchronize(s));
@@ -810,6 +848,11 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     // (the leaves' records follow those of the inner nodes and empty leaves)
     if ((uint64_t)h_counters[C_PAIRS] + n_leaves > cap_pairs) { err = "node list too small"; grow_leaves = std::min(grow_leaves * 4, 1 << 20); return 1; }
     for (int k = 0; k < 6; k++) tree.root_box[k] = key_value(hk[k]);
+    {
+        float raw[6];
+        memcpy(raw, h_counters + C_WORDS + 12, sizeof raw);
+        kd_overhang_with_margin(raw, tree.root_box, tree.over);
+    }
     tree.n_internal = 0;
     int real_levels = 0;   // a tree that got shallower leaves the last predicted levels without nodes
     for (int d = 0; d < levels; d++) {

@@ -96,6 +96,11 @@ struct SceneDev {
     float ambient[4], bg[4];
     float cam[4], r00[4], r01[4], r10[4], r11[4];
     float box_lo[4], box_hi[4];
+    // Overhang of the tree: the largest amount by which a face listed by a leaf reaches below (over_lo) / above (over_hi)
+    // that leaf's cell, per axis, on the float32 vertices and the float32 cells the walk uses, plus a safety margin for
+    // the rounding of the triangle test (1/256 of the root box's largest side; the walk adds 1/256 of the distance).
+    // Infinity switches pruning off.
+    float over_lo[4], over_hi[4];
     const PrimDev *prims;
     const MatDev *mats;
     const LightDev *lights;

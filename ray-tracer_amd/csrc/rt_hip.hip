@@ -99,6 +99,7 @@ struct rt_ctx {
     int walk_waves_per_cu = RT_WALK_WAVES_PER_CU;
     uint32_t first_level_rays = 0;               // capacity of the deeper levels on the first frame (0 = level 0's), rt_set_option
     bool stage_timing = true;                    // events around every stage kernel (rt_stats.level_stage_ms)
+    bool prune = true;                           // the closest-hit walk skips subtrees that cannot hold the nearest hit (rt_set_option "prune")
     bool stage_timed = false;                    // the frame in flight was queued with them
     int n_parts = 1;
     Part parts[MAX_PARTS];
@@ -128,6 +129,8 @@ struct rt_ctx {
     TriTag *d_ltag = nullptr;                    // ... and material, face, leaf code for the winners
     uint2 *d_path_first = nullptr;               // staging of (path code, first slot) pairs
     uint32_t *d_path_slot = nullptr;             // 2^PATH_BITS entries, SceneDev::path_slot
+    float over[6] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY};   // SceneDev::over_lo / over_hi of the host-built tree
+    bool over_valid = false;
     SharedTree *shared = nullptr;                // d_nodes, d_lgeo, d_ltag and d_path_slot belong to this shared copy, not to the context
     bool tree_dirty = true;
     size_t cap_prims = 0, cap_mats = 0, cap_lights = 0, cap_tris = 0, cap_path_first = 0;
@@ -290,6 +293,47 @@ int device_build(rt_ctx *ctx) {
     return 0;
 }
 
+// SceneDev::over_lo / over_hi of a host-built tree: the cells are the float32 boxes the walk's planes cut out of the
+// float32 root box, the vertices the float32 ones the triangle tests read.
+void tree_overhang(rt_ctx *ctx, const KdTreeHost &kd) {
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    struct Item { uint32_t node; float bmin[3], bmax[3]; };
+    std::vector<Item> todo;
+    Item root{0u, {(float)kd.root_box[0], (float)kd.root_box[1], (float)kd.root_box[2]},
+              {(float)kd.root_box[3], (float)kd.root_box[4], (float)kd.root_box[5]}};
+    if (!kd.nodes.empty()) todo.push_back(root);
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        const KdNodeDev &n = kd.nodes[it.node];
+        const uint32_t ty = n.info >> 30;
+        if (ty == 1u) {
+            const uint32_t a = (n.info >> 28) & 3u, child = n.info & 0x0fffffffu;
+            Item c0 = it, c1 = it;
+            c0.node = child; c0.bmax[a] = n.split;
+            c1.node = child + 1; c1.bmin[a] = n.split;
+            todo.push_back(c0);
+            todo.push_back(c1);
+        } else if (ty == 3u) {
+            const KdLeafDev &lf = kd.leaves[n.info & 0x3fffffffu];
+            for (int k = 0; k < 4; k++) {
+                if (lf.face[k] < 0) continue;
+                for (int j = 0; j < 3; j++) {
+                    const double *v = &ctx->verts[3 * (size_t)ctx->faces[3 * (size_t)lf.face[k] + j]];
+                    for (int c = 0; c < 3; c++) {
+                        const float x = (float)v[c];
+                        lo[c] = std::max(lo[c], it.bmin[c] - x);
+                        hi[c] = std::max(hi[c], x - it.bmax[c]);
+                    }
+                }
+            }
+        }
+    }
+    const float raw[6] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
+    kd_overhang_with_margin(raw, kd.root_box, ctx->over);
+    ctx->over_valid = true;
+}
+
 int upload_scene(rt_ctx *ctx) {
     // material index per primitive / per face is resolved here: (type, id) -> slot in the table
     auto find_mat = [&](int type, int id) -> int32_t {
@@ -417,6 +461,7 @@ int upload_scene(rt_ctx *ctx) {
                 path_first.push_back(make_uint2(code, first[li]));
             }
         }
+        tree_overhang(ctx, kd);
         detach_shared_tree(ctx);
         unsigned long long hash = fnv1a(nodes.data(), nodes.size() * sizeof(KdNodeDev));
         hash = fnv1a(lgeo.data(), lgeo.size() * sizeof(TriGeo), hash);
@@ -489,6 +534,11 @@ int upload_scene(rt_ctx *ctx) {
             h.box_lo[k] = (float)rb[k];
             h.box_hi[k] = (float)rb[3 + k];
         }
+    }
+    for (int k = 0; k < 3; k++) {
+        const float *ov = ctx->kd_on_device ? ctx->gpu_kd->tree.over : ctx->over;
+        h.over_lo[k] = ctx->prune ? ov[k] : INFINITY;
+        h.over_hi[k] = ctx->prune ? ov[3 + k] : INFINITY;
     }
     h.prims = ctx->d_prims; h.mats = ctx->d_mats; h.lights = ctx->d_lights; h.tris = ctx->d_tris;
     h.nodes = ctx->d_nodes; h.lgeo = ctx->d_lgeo; h.ltag = ctx->d_ltag; h.path_slot = ctx->d_path_slot;
@@ -770,10 +820,12 @@ int rt_build_kdtree(rt_ctx *ctx) {
     if (ctx->host_only) {
         ctx->st.kd_build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         ctx->kd_built = true;
+        ctx->over_valid = false;
         return 0;
     }
     ctx->st.kd_build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     ctx->tree_dirty = true;
+    ctx->over_valid = false;
     ctx->kd_built = true;
     ctx->scene_dirty = true;
     return 0;
@@ -789,6 +841,15 @@ int rt_kdtree_counts(rt_ctx *ctx, int64_t *n_nodes, int64_t *n_leaves) {
     }
     if (n_nodes) *n_nodes = ctx->kd.n_nodes;
     if (n_leaves) *n_leaves = (int64_t)ctx->kd.leaves.size();
+    return 0;
+}
+
+int rt_kdtree_overhang(rt_ctx *ctx, float out[6]) {
+    if (!ctx) return -1;
+    if (!out) return fail(ctx, "rt_kdtree_overhang: null argument");
+    if (!ctx->kd_built) return fail(ctx, "rt_kdtree_overhang: no tree built");
+    if (!ctx->kd_on_device && !ctx->over_valid) tree_overhang(ctx, ctx->kd);
+    memcpy(out, ctx->kd_on_device ? ctx->gpu_kd->tree.over : ctx->over, 6 * sizeof(float));
     return 0;
 }
 
@@ -1266,6 +1327,11 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
     if (!strcmp(name, "first_level_rays")) {
         if (!(value >= 0 && value <= 2147483392.0)) return fail(ctx, "rt_set_option: capacity out of range");
         ctx->first_level_rays = (uint32_t)value;
+        return 0;
+    }
+    if (!strcmp(name, "prune")) {
+        ctx->prune = value != 0.0;
+        ctx->scene_dirty = true;
         return 0;
     }
     if (!strcmp(name, "stage_timing")) {

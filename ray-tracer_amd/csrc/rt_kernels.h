@@ -69,7 +69,7 @@ struct LevelCounters {
     uint32_t shaded, pad5[31];
     uint32_t rec_count[2], pad6[30];      // leaf records tested by the closest / shadow walk (statistics)
     uint32_t xq[2][8][32];                // per job and eighth of the queue: cursor (one per 128-byte line)
-    unsigned long long walk_iters[2], walk_visits[2], walk_t0[2], walk_t1[2], walk_tsum[2], pad7[6];   // RT_WALK_STATS builds only: wave iterations, lane node visits, first start / last end / summed lifetime of the waves (100 MHz ticks)
+    unsigned long long walk_iters[2], walk_visits[2], walk_t0[2], walk_t1[2], walk_tsum[2], walk_pruned[2], pad7[4];   // RT_WALK_STATS builds only: wave iterations, lane node visits, first start / last end / summed lifetime of the waves (100 MHz ticks)
 };
 
 // Lanes per workgroup of the one-lane-per-ray kernels: the largest size; the host picks the size of a launch
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_gen_prims(LevelArgs A) {
         A.cur.best[tid] = ~0ull;
     }
     const uint32_t slot = block_reserve(to_kd, &A.cnt->kdq_count, s_wave);
-    if (to_kd) A.kdq[slot] = make_uint4(tid, __float_as_uint(kd_t0), __float_as_uint(kd_t1), 0u);
+    if (to_kd) A.kdq[slot] = make_uint4(tid, __float_as_uint(kd_t0), __float_as_uint(kd_t1), __float_as_uint(tMin));
 }
 
 // ---- k-d walk ----------------------------------------------------------------------------------------
@@ -346,6 +346,15 @@ constexpr uint32_t TEST_MIN_DRY = RT_TEST_MIN_DRY;   // records that trigger a t
 // rank of this lane among the set bits of a wave mask
 #define RANK_IN(mask) __builtin_amdgcn_mbcnt_hi((uint32_t)((mask) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(mask), 0u))
 
+// Pruning margins of a ray, one per axis: overhang of the listed faces on the side the ray comes from, as a distance
+// along the ray. A zero or NaN direction component gives infinity or NaN: such an axis never prunes.
+constexpr float PRUNE_KEEP = 1.0f - 1.0f / 256.0f;   // relative part of the safety margin (see SceneDev::over_lo)
+__device__ __forceinline__ void prune_margins(const SceneDev &S, float dx, float dy, float dz, float &wx, float &wy, float &wz) {
+    wx = (dx > 0.0f ? S.over_lo[0] : S.over_hi[0]) / fabsf(dx);
+    wy = (dy > 0.0f ? S.over_lo[1] : S.over_hi[1]) / fabsf(dy);
+    wz = (dz > 0.0f ? S.over_lo[2] : S.over_hi[2]) / fabsf(dz);
+}
+
 // One round of triangle tests: lanes 0 .. n-1 take the n oldest records of the ring. Every lane of the wave must
 // call it (the permutes read the registers of lanes that test nothing themselves). Returns true in the lanes whose
 // OWN shadow ray was found occluded in this round.
@@ -386,6 +395,9 @@ __device__ __forceinline__ bool test_round(const SceneDev &S, const WalkJob &J, 
         } else {
             // low word: visit rank of this leaf for this ray (see path_code), then the face's position in the leaf
             atomicMin(&J.best[rref], key | (unsigned long long)((S.ltag[first].code ^ near_upper_levels(rd)) << 2));
+#ifndef RT_NO_PRUNE
+            atomicMin(&hit_flag[src], (uint32_t)(key >> 32));   // the owner's nearest distance so far (prunes its walk)
+#endif
         }
     }
     bool mine = false;
@@ -395,6 +407,9 @@ __device__ __forceinline__ bool test_round(const SceneDev &S, const WalkJob &J, 
         if (mine) hit_flag[lane] = 0u;
         __syncthreads();
     }
+#ifndef RT_NO_PRUNE
+    else __syncthreads();   // one wave per workgroup: the minima above land before the owners read their slots
+#endif
     return mine;
 }
 
@@ -434,6 +449,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
     float tmin = 0.0f, tmax = 0.0f, maxDist = 0.0f;
     uint32_t ref = 0;
+    float tbest = 0.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;   // closest-hit job: see "pruning" below
     uint32_t info = 0;                       // node the lane stands on; 0 (no node has it) = the lane has no ray
     float split = 0.0f;
     int32_t sp_top = 0, sp_lo = 0;           // ring stack: entries sp_lo .. sp_top-1 are valid (at most SHORT_STACK)
@@ -442,7 +458,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
     uint32_t my_last = 0;                    // ring position just behind this lane's newest record
     uint32_t n_records = 0;                  // wave-uniform: records tested (statistics)
 #ifdef RT_WALK_STATS
-    unsigned long long st_iters = 0, st_visits = 0;
+    unsigned long long st_iters = 0, st_visits = 0, st_pruned = 0;
     const unsigned long long st_begin = wall_clock64();
 #endif
 
@@ -457,6 +473,9 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
             ring_head = UNIFORM(ring_head + n);
             n_records += n;
             if (ANY && mine) info = 0u;   // occluded: whatever else lies along the ray cannot change the bit
+#ifndef RT_NO_PRUNE
+            if (!ANY) tbest = __uint_as_float(hit_flag[lane]);
+#endif
         }
         // ---- refill: while the global queue has rays, as soon as enough lanes are free. A lane is free when its ray
         //      is finished AND none of its records is still waiting in the ring (those name its ray registers)
@@ -489,7 +508,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
                                 ? __uint_as_float(stack[((uint32_t)(sp_lo + 1) & (SHORT_STACK - 1)) * WAVE].y) : tmax;
                             mail[g] = make_uint4(bot.x, __float_as_uint(start), bot.y, ref);
                             mail[MAIL_SLOTS + g] = make_uint4(__float_as_uint(maxDist), __float_as_uint(ox), __float_as_uint(oy), __float_as_uint(oz));
-                            mail[2 * MAIL_SLOTS + g] = make_uint4(__float_as_uint(dx), __float_as_uint(dy), __float_as_uint(dz), 0u);
+                            mail[2 * MAIL_SLOTS + g] = make_uint4(__float_as_uint(dx), __float_as_uint(dy), __float_as_uint(dz), __float_as_uint(tbest));
                             sp_lo += 1;
                             maxDist = start;
                         }
@@ -502,6 +521,13 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
                         maxDist = __uint_as_float(m1.x);
                         ox = __uint_as_float(m1.y); oy = __uint_as_float(m1.z); oz = __uint_as_float(m1.w);
                         dx = __uint_as_float(m2.x); dy = __uint_as_float(m2.y); dz = __uint_as_float(m2.z);
+#ifndef RT_NO_PRUNE
+                        if (!ANY) {   // the taker goes on with what the giver knows about the ray
+                            tbest = __uint_as_float(m2.w);
+                            hit_flag[lane] = m2.w;
+                            prune_margins(S, dx, dy, dz, wx, wy, wz);
+                        }
+#endif
                         // the taker stands on a pretended empty leaf that ends where the stretch begins, with the
                         // stretch as the only entry of its stack: the tree action below pops it and fetches the node
                         tmin = tmax = __uint_as_float(m0.y);
@@ -567,6 +593,14 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
                         const float4 fo = J.rays[2 * (size_t)ref], fd = J.rays[2 * (size_t)ref + 1];
                         ox = fo.x; oy = fo.y; oz = fo.z;
                         dx = fd.x; dy = fd.y; dz = fd.z;
+#ifndef RT_NO_PRUNE
+                        // nearest distance known so far: the analytic winner's (a mesh hit must be strictly nearer,
+                        // js/8-kd_tree.js:948-949). A negative one (inside a cube) beats every triangle: 0 prunes everything
+                        const float seed = __uint_as_float(e.w);
+                        tbest = seed > 0.0f ? seed : 0.0f;
+                        hit_flag[lane] = __float_as_uint(tbest);
+                        prune_margins(S, dx, dy, dz, wx, wy, wz);
+#endif
                     }
                     tmax = maxDist;
                     sp_top = sp_lo = 0;
@@ -595,11 +629,26 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
             const bool pop = cont && sp_top != sp_lo;
             uint2 e = make_uint2(0u, __float_as_uint(maxDist));   // ring ran dry: restart at the root up to maxDist
             if (pop) e = stack[((uint32_t)(sp_top - 1) & (SHORT_STACK - 1)) * WAVE];
+#ifndef RT_NO_PRUNE
+            // pruning (closest-hit job): the entry is the far child of a node split on axis ea, entered at distance tmax.
+            // No face listed below it reaches back across that plane by more than the tree's overhang on that axis, so
+            // no hit below it is nearer than tmax - w[ea]; if the ray already holds a hit that near, the subtree is
+            // skipped: the lane stands on a pretended empty leaf that ends where the subtree's stretch ends.
+            // A restart (ring ran dry) has no plane; every cell still to come is entered across SOME plane beyond tmax.
+            bool pruned = false, dead = false;
+            if (!ANY) {
+                const uint32_t ea = (e.x >> 28) & 3u;
+                const float wa = ea == 0u ? wx : (ea == 1u ? wy : wz);
+                const float lim = tmax * PRUNE_KEEP;
+                pruned = pop && tbest <= lim - wa;
+                dead = cont && !pop && tbest <= lim - fmaxf(fmaxf(wx, wy), wz);
+            }
+#endif
             // both children of an internal node sit in one aligned 16-byte slot pair (a popped node shares such a pair with
             // its sibling): the load is issued before the plane distance is known and the choice is made in registers,
             // which takes the division out of the dependent chain of a ray (what a launch over few rays waits for)
             // (every lane fetches: a lane without a ray or at the end of its ray has e.x = 0 and reads the root's pair)
-            const uint4 pair = *reinterpret_cast<const uint4 *>(nodes + (is_int ? (info & 0x0fffffffu) : (e.x & ~1u)));
+            const uint4 pair = *reinterpret_cast<const uint4 *>(nodes + (is_int ? (info & 0x0fffffffu) : (e.x & 0x0ffffffeu)));
             // internal node: classify the children and pick the side(s) the ray interval touches
             const uint32_t a = (info >> 28) & 3u;
             const float o = a == 0u ? ox : (a == 1u ? oy : oz), d = a == 0u ? dx : (a == 1u ? dy : dz);
@@ -610,7 +659,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
             const bool both = is_int && !ge && !le;
             // which of the pair the lane goes on with is decided on wave masks: the far child alone = the other one
             const bool upper = cont ? (e.x & 1u) != 0u : ((le && !ge) != neg);
-            if (both) stack[((uint32_t)sp_top & (SHORT_STACK - 1)) * WAVE] = make_uint2(child + (neg ? 0u : 1u), __float_as_uint(tmax));
+            if (both) stack[((uint32_t)sp_top & (SHORT_STACK - 1)) * WAVE] = make_uint2((child + (neg ? 0u : 1u)) | (a << 28), __float_as_uint(tmax));
             // leaf with faces: note it (below), then go on with the next cell of the ray
             const bool is_listed = info >= 0xc0000000u;
             const unsigned long long listed = __builtin_amdgcn_ballot_w64(is_listed);
@@ -624,6 +673,15 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
                 split = __uint_as_float(upper ? pair.z : pair.x);
                 info = upper ? pair.w : pair.y;
             }
+#ifndef RT_NO_PRUNE
+            if (!ANY) {
+                if (pruned) info = 0x80000000u;
+                if (dead) info = 0u;
+#ifdef RT_WALK_STATS
+                st_pruned += (unsigned long long)__popcll(__ballot(pruned));
+#endif
+            }
+#endif
 
             // ---- the leaves just entered: one record per non-empty leaf into the wave's ring (some lane lists in
             //      nearly every action, so there is no branch around this)
@@ -642,6 +700,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
     if (lane == 0) {
         atomicAdd(&J.cnt->walk_iters[ANY ? 1 : 0], st_iters);
         atomicAdd(&J.cnt->walk_visits[ANY ? 1 : 0], st_visits);
+        atomicAdd(&J.cnt->walk_pruned[ANY ? 1 : 0], st_pruned);
         const unsigned long long st_end = wall_clock64();
         atomicMax(&J.cnt->walk_t0[ANY ? 1 : 0], ~st_begin);   // counters start at zero: the minimum is kept as the maximum of the complement
         atomicMax(&J.cnt->walk_t1[ANY ? 1 : 0], st_end);
@@ -663,7 +722,11 @@ __global__ __launch_bounds__(WAVE) void k_kd_walk(WalkArgs A) {
     __syncthreads();
     // the closest-hit job first: its rays are the longer ones (none of them stops early), so the launch ends with the
     // shorter shadow walks (measured: 3 % off the launch, 7 % for a 1/8 shard)
-    if (A.job[1].enabled) walk_job<false>(A.S, A.job[1], s_stack + lane, s_mail, s_ring, s_hit, lane);
+    if (A.job[1].enabled) {
+        walk_job<false>(A.S, A.job[1], s_stack + lane, s_mail, s_ring, s_hit, lane);
+        s_hit[lane] = 0u;   // the closest-hit job keeps each lane's nearest distance there
+        __syncthreads();
+    }
     if (A.job[0].enabled) walk_job<true>(A.S, A.job[0], s_stack + lane, s_mail, s_ring, s_hit, lane);
 }
 
