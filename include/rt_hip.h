@@ -155,6 +155,14 @@ int rt_set_camera(rt_ctx *ctx, const float pos[3], const float ray00[3], const f
  * faces: n_faces*3 vertex indices; face_mat: n_faces*2 = (material type, material id). */
 int rt_set_mesh(rt_ctx *ctx, const double *verts, int32_t n_verts, const uint32_t *faces,
                 const uint32_t *face_mat, int32_t n_faces);
+/* The vertices moved, the tree stays: replaces the per-frame vertex upload of RayTracer.update
+ * (`vertsData[i*3+0] = g_verts[i].x ...` + texSubImage2D, js/8-kd_tree.js:2461-2479) on the frames between two rebuilds.
+ * The reference rebuilds its tree at most every 0.30 s (js/8-kd_tree.js:2494-2495); until then its shader fetches the
+ * NEW vertices through the OLD leaves and the old root box (js/8-kd_tree.js:2523-2533). This call does the same: the
+ * triangle records of the device are refilled from `verts` (n_verts*3 doubles, the same count and face list as the
+ * last rt_set_mesh) through the node and leaf tables as they stand; root box and tree do not change until the next
+ * rt_build_kdtree / rt_build_kdtree_device, which then builds from these vertices. Fails while a frame is in flight. */
+int rt_update_vertices(rt_ctx *ctx, const double *verts, int32_t n_verts);
 /* builds the median-split tree over all faces and uploads the compact device layout */
 int rt_build_kdtree(rt_ctx *ctx);
 /* The same tree, bit for bit, built level by level on the GPU and left in device memory: for geometry that changes

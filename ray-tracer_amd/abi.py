@@ -136,6 +136,7 @@ def lib():
         L.rt_set_globals.argtypes = [vp, vp, vp]
         L.rt_set_camera.argtypes = [vp, vp, vp, vp, vp, vp]
         L.rt_set_mesh.argtypes = [vp, vp, i32, vp, vp, i32]
+        L.rt_update_vertices.argtypes = [vp, vp, i32]
         L.rt_build_kdtree.argtypes = [vp]
         L.rt_build_kdtree_device.argtypes = [vp]
         L.rt_kdtree_counts.argtypes = [vp, i64p, i64p]
@@ -235,6 +236,11 @@ class RayTracerHIP:
         f = np.ascontiguousarray(faces, np.uint32)
         m = np.ascontiguousarray(face_mat, np.uint32)
         self._ck(self.L.rt_set_mesh(self.ctx, v.ctypes.data, len(v), f.ctypes.data, m.ctypes.data, len(f)), "rt_set_mesh")
+
+    def updateVertices(self, verts):
+        """Moved vertices under the tree as it stands (what the reference renders between two k-d rebuilds)."""
+        v = np.ascontiguousarray(verts, np.float64)
+        self._ck(self.L.rt_update_vertices(self.ctx, v.ctypes.data, len(v)), "rt_update_vertices")
 
     def buildKdTree(self, on_device=False):
         if on_device:

@@ -29,6 +29,8 @@ struct GpuKdTree {
     uint32_t n_leaves = 0;
     double root_box[6] = {0, 0, 0, 0, 0, 0};
     float over[6] = {0, 0, 0, 0, 0, 0};   // SceneDev::over_lo / over_hi
+    const float *leaf_box = nullptr; // float32 cell of every leaf with faces (lo xyz, hi xyz), indexed by TriTag::leaf
+    const uint32_t *faces = nullptr; // the mesh's vertex indices, 3 per face
     int64_t n_internal = 0, n_leaf = 0, n_empty = 0;
     int depth = 0;
     double build_ms = 0;            // device time of the last build

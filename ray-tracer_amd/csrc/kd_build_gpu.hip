@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void k_kd_leaf_emit(const uint32_t *leaf_heap,
             TriGeo g;
             for (int c = 0; c < 3; c++) { g.v0[c] = t.v0[c]; g.e1[c] = t.e1[c]; g.e2[c] = t.e2[c]; }
             lgeo[first + k] = g;
-            ltag[first + k] = TriTag{t.mat, t.face, code, 0u};
+            ltag[first + k] = TriTag{t.mat, t.face, code, i};
         }
     }
     // the leaves' pair records follow those of the inner nodes and empty leaves, in leaf order
@@ -848,6 +848,8 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     // (the leaves' records follow those of the inner nodes and empty leaves)
     if ((uint64_t)h_counters[C_PAIRS] + n_leaves > cap_pairs) { err = "node list too small"; grow_leaves = std::min(grow_leaves * 4, 1 << 20); return 1; }
     for (int k = 0; k < 6; k++) tree.root_box[k] = key_value(hk[k]);
+    tree.leaf_box = leaf_box;
+    tree.faces = d_faces;
     {
         float raw[6];
         memcpy(raw, h_counters + C_WORDS + 12, sizeof raw);

@@ -55,7 +55,7 @@ struct TriTag {
     int32_t mat;
     int32_t face;
     uint32_t code;                // path code of the leaf that lists this slot (see path_code)
-    uint32_t pad;
+    uint32_t leaf;                // which entry of the leaf-cell table (6 floats: lo xyz, hi xyz) is this slot's leaf
 };
 
 // Position of a node in the tree as a bit string: one bit per level below the root, 0 = lower child, 1 = upper

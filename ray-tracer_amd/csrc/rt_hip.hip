@@ -31,23 +31,37 @@ thread_local std::string g_create_error;
 // registered; the last context to let go frees it.
 struct SharedTree {
     int device = 0;
-    unsigned long long hash = 0;
-    size_t n_nodes = 0, n_slots = 0;
+    unsigned long long hash = 0, sum = 0;        // two independent digests of the contents (see tree_digest)
+    size_t n_nodes = 0, n_slots = 0, n_leaves = 0;
+    size_t cap_nodes = 0, cap_slots = 0, cap_leaves = 0;
     KdNodeDev *nodes = nullptr;
     TriGeo *lgeo = nullptr;
     TriTag *ltag = nullptr;
     uint32_t *path_slot = nullptr;
+    float *leaf_box = nullptr;                   // float32 cell of every leaf with faces, indexed by TriTag::leaf
     int refs = 0;
 };
 std::mutex g_shared_mu;
 std::vector<SharedTree *> g_shared;
 
-unsigned long long fnv1a(const void *data, size_t n, unsigned long long h = 1469598103934665603ull) {
-    const unsigned long long *p = (const unsigned long long *)data;   // eight bytes a step: these are megabytes
-    for (size_t i = 0; i < n / 8; i++) { h ^= p[i]; h *= 1099511628211ull; }
+// Two digests over the same bytes, eight at a step (these are megabytes). A multiplication only carries a difference
+// upwards, so the product's high half is folded back into the low half after every word: a flipped bit anywhere reaches
+// every bit of the state. The second digest is a rotating sum, independent of the first: two trees are taken for the
+// same one only when both digests and all three sizes agree.
+struct Digest { unsigned long long h = 1469598103934665603ull, s = 0x9e3779b97f4a7c15ull; };
+void tree_digest(const void *data, size_t n, Digest &d) {
+    const unsigned long long *p = (const unsigned long long *)data;
+    for (size_t i = 0; i < n / 8; i++) {
+        d.h = (d.h ^ p[i]) * 1099511628211ull;
+        d.h ^= d.h >> 32;
+        d.s = ((d.s << 7) | (d.s >> 57)) + p[i] * 0xff51afd7ed558ccdull;
+    }
     const unsigned char *q = (const unsigned char *)data + (n / 8) * 8;
-    for (size_t i = 0; i < n % 8; i++) { h ^= q[i]; h *= 1099511628211ull; }
-    return h;
+    for (size_t i = 0; i < n % 8; i++) {
+        d.h = (d.h ^ q[i]) * 1099511628211ull;
+        d.h ^= d.h >> 32;
+        d.s = ((d.s << 7) | (d.s >> 57)) + q[i];
+    }
 }
 
 // Pipeline step k of a frame: k_gen_prims(level k), k_kd_walk (closest-hit rays of level k together with the shadow
@@ -127,6 +141,17 @@ struct rt_ctx {
     KdNodeDev *d_nodes = nullptr;
     TriGeo *d_lgeo = nullptr;                    // leaf-ordered triangles: geometry for the tests ...
     TriTag *d_ltag = nullptr;                    // ... and material, face, leaf code for the winners
+    const float *d_leaf_box = nullptr;           // float32 cells of the leaves, indexed by TriTag::leaf
+    size_t n_slots = 0;
+    // rt_update_vertices: float32 vertices and vertex indices on the device, a private copy of the leaf-ordered geometry
+    // (the shared one belongs to every context that holds the tree), six overhang maxima
+    float *d_v32 = nullptr;
+    uint32_t *d_faces_u32 = nullptr;
+    TriGeo *d_lgeo_own = nullptr;
+    uint32_t *d_over_bits = nullptr;
+    size_t cap_v32 = 0, cap_faces_u32 = 0, cap_lgeo_own = 0, cap_over_bits = 0;
+    bool faces_on_device = false;                // d_faces_u32 holds the current mesh's indices
+    bool tris_stale = true;                      // tris_host does not follow `verts` / the material table
     uint2 *d_path_first = nullptr;               // staging of (path code, first slot) pairs
     uint32_t *d_path_slot = nullptr;             // 2^PATH_BITS entries, SceneDev::path_slot
     float over[6] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY, INFINITY};   // SceneDev::over_lo / over_hi of the host-built tree
@@ -244,11 +269,12 @@ void detach_shared_tree(rt_ctx *ctx) {
         (void)hipFree(t->lgeo);
         (void)hipFree(t->ltag);
         (void)hipFree(t->path_slot);
+        (void)hipFree(t->leaf_box);
         g_shared.erase(std::remove(g_shared.begin(), g_shared.end(), t), g_shared.end());
         delete t;
     }
     ctx->shared = nullptr;
-    ctx->d_nodes = nullptr; ctx->d_lgeo = nullptr; ctx->d_ltag = nullptr; ctx->d_path_slot = nullptr;
+    ctx->d_nodes = nullptr; ctx->d_lgeo = nullptr; ctx->d_ltag = nullptr; ctx->d_path_slot = nullptr; ctx->d_leaf_box = nullptr;
 }
 
 int ensure_queues(rt_ctx *ctx, Part &P, int level, uint32_t n_rays, uint32_t n_lights) {
@@ -295,7 +321,32 @@ int device_build(rt_ctx *ctx) {
 
 // SceneDev::over_lo / over_hi of a host-built tree: the cells are the float32 boxes the walk's planes cut out of the
 // float32 root box, the vertices the float32 ones the triangle tests read.
-void tree_overhang(rt_ctx *ctx, const KdTreeHost &kd) {
+// triangles in face order on the host: float32 narrowing of the vertices (js/8-kd_tree.js:2462-2464), edges formed in
+// float32; per-face material slots resolved against the material table
+void refresh_tris_host(rt_ctx *ctx) {
+    if (!ctx->tris_stale) return;
+    auto find_mat = [&](int type, int id) -> int32_t {
+        for (size_t i = 0; i < ctx->mats_host.size(); i++)
+            if (ctx->mats_host[i].type == type && ctx->mats_host[i].id == id) return (int32_t)i;
+        return -1;
+    };
+    const size_t nf = ctx->faces.size() / 3;
+    ctx->tris_host.resize(nf);
+    for (size_t f = 0; f < nf; f++) {
+        float v[3][3];
+        for (int j = 0; j < 3; j++)
+            for (int k = 0; k < 3; k++) v[j][k] = (float)ctx->verts[3 * (size_t)ctx->faces[3 * f + j] + k];
+        TriDev &t = ctx->tris_host[f];
+        for (int k = 0; k < 3; k++) { t.v0[k] = v[0][k]; t.e1[k] = v[1][k] - v[0][k]; t.e2[k] = v[2][k] - v[0][k]; }
+        t.mat = find_mat((int)ctx->face_mat[2 * f], (int)ctx->face_mat[2 * f + 1]);
+        t.face = (int32_t)f;
+        t.pad = 0;
+    }
+    ctx->tris_stale = false;
+}
+
+void tree_overhang(rt_ctx *ctx, const KdTreeHost &kd, std::vector<float> *leaf_boxes = nullptr) {
+    if (leaf_boxes) leaf_boxes->assign(6 * kd.leaves.size(), 0.0f);
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     struct Item { uint32_t node; float bmin[3], bmax[3]; };
     std::vector<Item> todo;
@@ -316,6 +367,11 @@ void tree_overhang(rt_ctx *ctx, const KdTreeHost &kd) {
             todo.push_back(c1);
         } else if (ty == 3u) {
             const KdLeafDev &lf = kd.leaves[n.info & 0x3fffffffu];
+            if (leaf_boxes)
+                for (int c = 0; c < 3; c++) {
+                    (*leaf_boxes)[6 * (size_t)(n.info & 0x3fffffffu) + c] = it.bmin[c];
+                    (*leaf_boxes)[6 * (size_t)(n.info & 0x3fffffffu) + 3 + c] = it.bmax[c];
+                }
             for (int k = 0; k < 4; k++) {
                 if (lf.face[k] < 0) continue;
                 for (int j = 0; j < 3; j++) {
@@ -405,23 +461,12 @@ int upload_scene(rt_ctx *ctx) {
         ctx->mesh_dirty = false;
     }
     if (ctx->mesh_dirty) {
-        // triangles: float32 narrowing of the vertices (js/8-kd_tree.js:2462-2464), edges formed in float32
-        const size_t nf = ctx->faces.size() / 3;
-        std::vector<TriDev> tris(nf);
-        for (size_t f = 0; f < nf; f++) {
-            float v[3][3];
-            for (int j = 0; j < 3; j++)
-                for (int k = 0; k < 3; k++) v[j][k] = (float)ctx->verts[3 * (size_t)ctx->faces[3 * f + j] + k];
-            TriDev &t = tris[f];
-            for (int k = 0; k < 3; k++) { t.v0[k] = v[0][k]; t.e1[k] = v[1][k] - v[0][k]; t.e2[k] = v[2][k] - v[0][k]; }
-            t.mat = find_mat((int)ctx->face_mat[2 * f], (int)ctx->face_mat[2 * f + 1]);
-            t.face = (int32_t)f;
-            t.pad = 0;
-        }
+        ctx->tris_stale = true;
+        refresh_tris_host(ctx);
+        const size_t nf = ctx->tris_host.size();
         if (ensure(ctx, ctx->d_tris, ctx->cap_tris, nf)) return -1;
-        if (nf) HIPCK(hipMemcpyAsync(ctx->d_tris, tris.data(), nf * sizeof(TriDev), hipMemcpyHostToDevice, ctx->stream));
-        HIPCK(hipStreamSynchronize(ctx->stream));   // `tris` is a local
-        ctx->tris_host.swap(tris);
+        if (nf) HIPCK(hipMemcpyAsync(ctx->d_tris, ctx->tris_host.data(), nf * sizeof(TriDev), hipMemcpyHostToDevice, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
         ctx->mesh_dirty = false;
         ctx->tree_dirty = true;
     }
@@ -429,6 +474,7 @@ int upload_scene(rt_ctx *ctx) {
         // device form of the tree: leaves name a slot range of the leaf-ordered triangle array
         auto t0 = std::chrono::steady_clock::now();
         const KdTreeHost &kd = ctx->kd;
+        refresh_tris_host(ctx);
         std::vector<uint32_t> first(kd.leaves.size() + 1, 0);
         for (size_t i = 0; i < kd.leaves.size(); i++) {
             uint32_t c = 0;
@@ -444,7 +490,7 @@ int upload_scene(rt_ctx *ctx) {
                 if (kd.leaves[i].face[k] > -1) {
                     const TriDev &t = ctx->tris_host[(size_t)kd.leaves[i].face[k]];
                     memcpy(lgeo[s0].v0, t.v0, sizeof(TriGeo));   // v0, e1, e2 lie in this order in both records
-                    ltag[s0] = TriTag{t.mat, t.face, 0u, 0u};
+                    ltag[s0] = TriTag{t.mat, t.face, 0u, (uint32_t)i};
                     s0++;
                 }
         }
@@ -461,38 +507,65 @@ int upload_scene(rt_ctx *ctx) {
                 path_first.push_back(make_uint2(code, first[li]));
             }
         }
-        tree_overhang(ctx, kd);
-        detach_shared_tree(ctx);
-        unsigned long long hash = fnv1a(nodes.data(), nodes.size() * sizeof(KdNodeDev));
-        hash = fnv1a(lgeo.data(), lgeo.size() * sizeof(TriGeo), hash);
-        hash = fnv1a(ltag.data(), ltag.size() * sizeof(TriTag), hash);
-        {   // another context of this process may hold this very tree on this GPU already
+        std::vector<float> leaf_box;
+        tree_overhang(ctx, kd, &leaf_box);
+        Digest dg;
+        tree_digest(nodes.data(), nodes.size() * sizeof(KdNodeDev), dg);
+        tree_digest(lgeo.data(), lgeo.size() * sizeof(TriGeo), dg);
+        tree_digest(ltag.data(), ltag.size() * sizeof(TriTag), dg);
+        const size_t n_leaves = kd.leaves.size();
+        SharedTree *mine = nullptr;   // the copy this context may overwrite: it is its only holder and the new tree fits
+        {
+            std::lock_guard<std::mutex> lock(g_shared_mu);
+            SharedTree *old = ctx->shared;
+            if (old && old->refs == 1 && old->device == ctx->cfg.device && old->cap_nodes >= nodes.size() &&
+                old->cap_slots >= lgeo.size() && old->cap_leaves >= n_leaves)
+                mine = old;
+        }
+        if (!mine) detach_shared_tree(ctx);
+        if (!mine) {   // another context of this process may hold this very tree on this GPU already
             std::lock_guard<std::mutex> lock(g_shared_mu);
             for (SharedTree *t : g_shared)
-                if (t->device == ctx->cfg.device && t->hash == hash && t->n_nodes == nodes.size() && t->n_slots == lgeo.size()) {
+                if (t->device == ctx->cfg.device && t->hash == dg.h && t->sum == dg.s && t->n_nodes == nodes.size() &&
+                    t->n_slots == lgeo.size() && t->n_leaves == n_leaves) {
                     t->refs++;
                     ctx->shared = t;
                     break;
                 }
         }
-        if (!ctx->shared) {
-            SharedTree *t = new SharedTree();
-            t->device = ctx->cfg.device; t->hash = hash; t->n_nodes = nodes.size(); t->n_slots = lgeo.size(); t->refs = 1;
-            auto drop = [&]() { (void)hipFree(t->nodes); (void)hipFree(t->lgeo); (void)hipFree(t->ltag); (void)hipFree(t->path_slot); delete t; };
-            hipError_t e;
-            if ((e = hipMalloc((void **)&t->nodes, std::max<size_t>(nodes.size(), 1) * sizeof(KdNodeDev))) != hipSuccess ||
-                (e = hipMalloc((void **)&t->lgeo, std::max<size_t>(lgeo.size(), 1) * sizeof(TriGeo))) != hipSuccess ||
-                (e = hipMalloc((void **)&t->ltag, std::max<size_t>(ltag.size(), 1) * sizeof(TriTag))) != hipSuccess ||
-                (e = hipMalloc((void **)&t->path_slot, sizeof(uint32_t) << PATH_BITS)) != hipSuccess) {
-                drop();
-                return fail(ctx, (std::string("hipMalloc (k-d tree): ") + hipGetErrorString(e)).c_str());
+        if (mine || !ctx->shared) {
+            SharedTree *t = mine;
+            auto drop = [&]() {
+                if (mine) { detach_shared_tree(ctx); return; }   // (the only holder lets go: the buffers are freed there)
+                (void)hipFree(t->nodes); (void)hipFree(t->lgeo); (void)hipFree(t->ltag); (void)hipFree(t->path_slot); (void)hipFree(t->leaf_box);
+                delete t;
+            };
+            hipError_t e = hipSuccess;
+            if (!t) {
+                // a tree that is rebuilt again and again (moving geometry) keeps its buffers: a quarter of room to grow into
+                t = new SharedTree();
+                t->device = ctx->cfg.device;
+                t->cap_nodes = std::max<size_t>(nodes.size() + nodes.size() / 4, 1);
+                t->cap_slots = std::max<size_t>(lgeo.size() + lgeo.size() / 4, 1);
+                t->cap_leaves = std::max<size_t>(n_leaves + n_leaves / 4, 1);
+                if ((e = hipMalloc((void **)&t->nodes, t->cap_nodes * sizeof(KdNodeDev))) != hipSuccess ||
+                    (e = hipMalloc((void **)&t->lgeo, t->cap_slots * sizeof(TriGeo))) != hipSuccess ||
+                    (e = hipMalloc((void **)&t->ltag, t->cap_slots * sizeof(TriTag))) != hipSuccess ||
+                    (e = hipMalloc((void **)&t->leaf_box, t->cap_leaves * 6 * sizeof(float))) != hipSuccess ||
+                    (e = hipMalloc((void **)&t->path_slot, sizeof(uint32_t) << PATH_BITS)) != hipSuccess) {
+                    drop();
+                    return fail(ctx, (std::string("hipMalloc (k-d tree): ") + hipGetErrorString(e)).c_str());
+                }
             }
+            t->hash = dg.h; t->sum = dg.s; t->n_nodes = nodes.size(); t->n_slots = lgeo.size(); t->n_leaves = n_leaves;
             if (ensure(ctx, ctx->d_path_first, ctx->cap_path_first, path_first.size())) { drop(); return -1; }
             e = hipMemcpyAsync(t->nodes, nodes.data(), nodes.size() * sizeof(KdNodeDev), hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess && !lgeo.empty())
                 e = hipMemcpyAsync(t->lgeo, lgeo.data(), lgeo.size() * sizeof(TriGeo), hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess && !ltag.empty())
                 e = hipMemcpyAsync(t->ltag, ltag.data(), ltag.size() * sizeof(TriTag), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess && !leaf_box.empty())
+                e = hipMemcpyAsync(t->leaf_box, leaf_box.data(), leaf_box.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess && !path_first.empty()) {
                 // only the entries of existing leaves are ever read, so the table is not cleared
                 e = hipMemcpyAsync(ctx->d_path_first, path_first.data(), path_first.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream);
@@ -504,11 +577,16 @@ int upload_scene(rt_ctx *ctx) {
             }
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the sources are locals; the copy is complete before anyone shares it
             if (e != hipSuccess) { drop(); return fail(ctx, (std::string("k-d tree upload: ") + hipGetErrorString(e)).c_str()); }
-            std::lock_guard<std::mutex> lock(g_shared_mu);
-            g_shared.push_back(t);
-            ctx->shared = t;
+            if (!mine) {
+                t->refs = 1;
+                std::lock_guard<std::mutex> lock(g_shared_mu);
+                g_shared.push_back(t);
+                ctx->shared = t;
+            }
         }
         ctx->d_nodes = ctx->shared->nodes; ctx->d_lgeo = ctx->shared->lgeo; ctx->d_ltag = ctx->shared->ltag; ctx->d_path_slot = ctx->shared->path_slot;
+        ctx->d_leaf_box = ctx->shared->leaf_box;
+        ctx->n_slots = lgeo.size();
         HIPCK(hipStreamSynchronize(ctx->stream));
         ctx->st.kd_upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         ctx->tree_dirty = false;
@@ -698,7 +776,7 @@ void rt_destroy(rt_ctx *ctx) {
     (void)hipDeviceSynchronize();
     delete ctx->gpu_kd;
     detach_shared_tree(ctx);
-    void *ptrs[] = {ctx->d_scene, ctx->d_prims, ctx->d_mats, ctx->d_lights, ctx->d_tris,
+    void *ptrs[] = {ctx->d_scene, ctx->d_prims, ctx->d_mats, ctx->d_lights, ctx->d_tris, ctx->d_v32, ctx->d_faces_u32, ctx->d_lgeo_own, ctx->d_over_bits,
                     ctx->d_path_first, ctx->d_fb, ctx->d_rgba, ctx->d_hit, ctx->d_compact, ctx->d_compact_canvas, ctx->d_canvas,
                     ctx->d_part_sum, ctx->d_part_cnt, ctx->d_tone_out, ctx->d_tone_cnt,
                     ctx->d_tone_pair, ctx->d_tone, ctx->d_tone_d};
@@ -791,6 +869,72 @@ int rt_set_mesh(rt_ctx *ctx, const double *verts, int32_t n_verts, const uint32_
     ctx->kd_on_device = false;
     ctx->mesh_dirty = true;
     ctx->scene_dirty = true;
+    ctx->faces_on_device = false;
+    ctx->over_valid = false;
+    return 0;
+}
+
+int rt_update_vertices(rt_ctx *ctx, const double *verts, int32_t n_verts) {
+    if (!ctx) return -1;
+    if (n_verts < 0 || (n_verts > 0 && !verts)) return fail(ctx, "rt_update_vertices: bad arguments");
+    if ((size_t)n_verts * 3 != ctx->verts.size()) return fail(ctx, "rt_update_vertices: the mesh has another number of vertices (use rt_set_mesh)");
+    if (ctx->in_flight) return fail(ctx, "rt_update_vertices: a frame is in flight, call rt_trace_end first");
+    ctx->verts.assign(verts, verts + (size_t)n_verts * 3);
+    ctx->tris_stale = true;
+    ctx->over_valid = false;
+    ctx->scene_dirty = true;
+    const size_t nf = ctx->faces.size() / 3;
+    // nothing of this mesh is on the device yet (or no device at all): the next upload takes the new vertices, through
+    // whatever tree the context holds
+    if (ctx->host_only || ctx->mesh_dirty || nf == 0) { ctx->mesh_dirty = true; return 0; }
+    HIPCK(hipSetDevice(ctx->cfg.device));
+    hipStream_t s = ctx->stream;
+    std::vector<float> v32((size_t)n_verts * 3);
+    for (size_t i = 0; i < v32.size(); i++) v32[i] = (float)verts[i];   // vertsData[i*3+0] = g_verts[i].x, js/8-kd_tree.js:2462-2464
+    if (ensure(ctx, ctx->d_v32, ctx->cap_v32, v32.size())) return -1;
+    if (ensure(ctx, ctx->d_over_bits, ctx->cap_over_bits, 6)) return -1;
+    HIPCK(hipMemcpyAsync(ctx->d_v32, v32.data(), v32.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    const bool dev_tree = ctx->kd_on_device && ctx->kd_built;
+    const uint32_t *d_faces = dev_tree ? ctx->gpu_kd->tree.faces : nullptr;
+    if (!d_faces) {
+        if (!ctx->faces_on_device) {
+            if (ensure(ctx, ctx->d_faces_u32, ctx->cap_faces_u32, ctx->faces.size())) return -1;
+            HIPCK(hipMemcpyAsync(ctx->d_faces_u32, ctx->faces.data(), ctx->faces.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            ctx->faces_on_device = true;
+        }
+        d_faces = ctx->d_faces_u32;
+    }
+    TriDev *tris = dev_tree ? ctx->gpu_kd->tree.tris : ctx->d_tris;
+    hipLaunchKernelGGL(k_refill_tris, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, tris, d_faces, ctx->d_v32, (uint32_t)nf);
+    const bool have_tree = ctx->kd_built && !ctx->tree_dirty && (dev_tree || ctx->shared);
+    if (have_tree) {
+        // the leaf-ordered records through the tree as it stands (the reference's shader reads the new vertices through
+        // the old leaves until the next rebuild, js/8-kd_tree.js:2494-2533), and the old tree's overhang for the new vertices
+        const size_t n_slots = dev_tree ? ctx->gpu_kd->tree.n_slots : ctx->n_slots;
+        TriGeo *lgeo;
+        const TriTag *ltag;
+        const float *boxes;
+        if (dev_tree) {
+            lgeo = ctx->gpu_kd->tree.lgeo; ltag = ctx->gpu_kd->tree.ltag; boxes = ctx->gpu_kd->tree.leaf_box;
+        } else {
+            if (ensure(ctx, ctx->d_lgeo_own, ctx->cap_lgeo_own, n_slots)) return -1;
+            lgeo = ctx->d_lgeo_own; ltag = ctx->d_ltag; boxes = ctx->d_leaf_box;
+            ctx->d_lgeo = ctx->d_lgeo_own;
+        }
+        HIPCK(hipMemsetAsync(ctx->d_over_bits, 0, 6 * sizeof(uint32_t), s));
+        if (n_slots)
+            hipLaunchKernelGGL(k_refill_slots, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, lgeo, ltag, d_faces, ctx->d_v32,
+                               (uint32_t)n_slots, boxes, ctx->d_over_bits);
+        HIPCK(hipGetLastError());
+        float raw[6];
+        HIPCK(hipMemcpyAsync(raw, ctx->d_over_bits, sizeof raw, hipMemcpyDeviceToHost, s));
+        HIPCK(hipStreamSynchronize(s));
+        if (dev_tree) kd_overhang_with_margin(raw, ctx->gpu_kd->tree.root_box, ctx->gpu_kd->tree.over);
+        else { kd_overhang_with_margin(raw, ctx->kd.root_box, ctx->over); ctx->over_valid = true; }
+    } else {
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(s));   // v32 is a local
+    }
     return 0;
 }
 

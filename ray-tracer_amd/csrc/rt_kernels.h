@@ -736,6 +736,53 @@ __global__ __launch_bounds__(256) void k_fill_path_slots(const uint2 *pairs, uin
     if (i < n) table[pairs[i].x] = pairs[i].y;
 }
 
+// ---- moved vertices under an unchanged tree (rt_update_vertices) ------------------------------------------------------
+// The reference uploads the vertex array every frame and rebuilds the tree at most every 0.30 s
+// (js/8-kd_tree.js:2459-2522): in between, its shader fetches fresh vertices through the old leaves. Here the triangle
+// records hold vertices, so they are refilled: the face-ordered table ...
+__global__ __launch_bounds__(256) void k_refill_tris(TriDev *tris, const uint32_t *faces, const float *verts, uint32_t n_faces) {
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_faces) return;
+    const float *a = verts + 3 * (size_t)faces[3 * (size_t)f], *b = verts + 3 * (size_t)faces[3 * (size_t)f + 1],
+                *c = verts + 3 * (size_t)faces[3 * (size_t)f + 2];
+    for (int k = 0; k < 3; k++) { tris[f].v0[k] = a[k]; tris[f].e1[k] = b[k] - a[k]; tris[f].e2[k] = c[k] - a[k]; }
+}
+// ... and the leaf-ordered one, together with the tree's new overhang (SceneDev::over_lo / over_hi): the moved faces may
+// reach much farther out of the old cells than before. over_bits: six float maxima as bit patterns (all >= 0), zeroed
+// by the caller.
+__global__ __launch_bounds__(256) void k_refill_slots(TriGeo *lgeo, const TriTag *ltag, const uint32_t *faces, const float *verts,
+                                                      uint32_t n_slots, const float *leaf_box, uint32_t *over_bits) {
+    __shared__ uint32_t s_over[6][4];
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    float over[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (s < n_slots) {
+        const TriTag tag = ltag[s];
+        const float *box = leaf_box + 6 * (size_t)tag.leaf;
+        const float *v[3];
+        for (int j = 0; j < 3; j++) v[j] = verts + 3 * (size_t)faces[3 * (size_t)tag.face + j];
+        TriGeo g;
+        for (int k = 0; k < 3; k++) {
+            g.v0[k] = v[0][k]; g.e1[k] = v[1][k] - v[0][k]; g.e2[k] = v[2][k] - v[0][k];
+            for (int j = 0; j < 3; j++) {
+                over[k] = fmaxf(over[k], box[k] - v[j][k]);
+                over[3 + k] = fmaxf(over[3 + k], v[j][k] - box[3 + k]);
+            }
+        }
+        lgeo[s] = g;
+    }
+    for (int c = 0; c < 6; c++) {
+        float m = over[c];
+        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63u) == 0u) s_over[c][threadIdx.x >> 6] = __float_as_uint(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6u) {
+        const uint32_t *w = s_over[threadIdx.x];
+        const uint32_t m = max(max(w[0], w[1]), max(w[2], w[3]));
+        if (m) atomicMax(&over_bits[threadIdx.x], m);
+    }
+}
+
 // ---- surface reconstruction ------------------------------------------------------------------------
 struct Surface {
     V3 point, normal, local;

@@ -209,6 +209,16 @@ static napi_value js_set_mesh(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+/* rt_update_vertices: moved vertices under the tree as it stands (the frames between two k-d rebuilds) */
+static napi_value js_update_vertices(napi_env env, napi_callback_info info) {
+    ARGS(2)
+    rt_ctx *ctx; void *v; size_t nv;
+    if (!get_ctx(env, argv[0], &ctx) || !get_bytes(env, argv[1], &v, &nv)) return NULL;
+    if (nv % 24) { napi_throw_type_error(env, NULL, "rt_update_vertices: expected Float64Array(3*nV)"); return NULL; }
+    if (rt_update_vertices(ctx, (const double *)v, (int32_t)(nv / 24)) != 0) return throw_rt(env, ctx, "rt_update_vertices");
+    return NULL;
+}
+
 #define CALL0(fn_name, rt_fn)                                            \
     static napi_value fn_name(napi_env env, napi_callback_info info) {   \
         ARGS(1)                                                          \
@@ -361,7 +371,7 @@ static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } table[] = {
         {"structSizes", js_struct_sizes}, {"defaultConfig", js_default_config}, {"create", js_create}, {"destroy", js_destroy},
         {"setPrimitives", js_set_primitives}, {"setMaterials", js_set_materials}, {"setLights", js_set_lights},
-        {"setGlobals", js_set_globals}, {"setCamera", js_set_camera}, {"setMesh", js_set_mesh},
+        {"setGlobals", js_set_globals}, {"setCamera", js_set_camera}, {"setMesh", js_set_mesh}, {"updateVertices", js_update_vertices},
         {"buildKdTree", js_build_kdtree}, {"buildKdTreeDevice", js_build_kdtree_device}, {"kdtreeCounts", js_kdtree_counts},
         {"exportKdTree", js_export_kdtree}, {"kdRootBox", js_kd_root_box},
         {"trace", js_trace}, {"traceBegin", js_trace_begin}, {"traceEnd", js_trace_end}, {"readFloat", js_read_float}, {"readRGBA8", js_read_rgba8}, {"readHitIds", js_read_hit_ids},

@@ -4,7 +4,7 @@
 //   constructor  render target allocation                         -> rt_create
 //   setScene     shader generation + texture allocation (:2347-2431) -> primitive / material tables
 //   update       uniform marshalling, vertex/face upload, k-d build, draw, readPixels, Lbar/sf loop (:2433-2573)
-//                -> rt_set_* / rt_set_mesh / rt_build_kdtree / rt_trace / rt_tone
+//                -> rt_set_* / rt_set_mesh / rt_update_vertices / rt_build_kdtree / rt_trace / rt_tone
 //   render       present draw (:2575-2589)                        -> rt_present into this.canvasPixels
 // There is no CPU path: if the addon cannot be loaded, requiring this module throws.
 const path = require('path');
@@ -49,6 +49,7 @@ function makeRayTracer(G, THREE, api) {
             this.Lbar = 0;
             this.sf = 0;
             this._meshKey = null;
+            this._treeVerts = null;
         }
 
         dispose() { addon.destroy(this.ctx); this.ctx = null; }
@@ -59,6 +60,7 @@ function makeRayTracer(G, THREE, api) {
             this.scene = scene;
             this.geometryUpdatedOnce = false;
             this._meshKey = null;
+            this._treeVerts = null;
         }
 
         // uniform dictionary exactly as the reference fills it (js/8-kd_tree.js:2435-2453)
@@ -123,16 +125,16 @@ function makeRayTracer(G, THREE, api) {
             addon.setCamera(this.ctx, new Float32Array([...vec3(u.cameraPos), ...vec3(u.ray00), ...vec3(u.ray01), ...vec3(u.ray10), ...vec3(u.ray11)]));
         }
 
-        // g_verts / g_faces -> rt_set_mesh + rt_build_kdtree. The reference re-uploads the arrays every frame
-        // and rebuilds the tree at most every 0.30 s (js/8-kd_tree.js:2459-2522), rendering moved vertices
-        // against a stale tree in between. Here geometry and tree always change together: when the packed
-        // arrays differ from the last upload and the rebuild interval (KD_REBUILD_INTERVAL, default the
-        // reference's 0.30 s; 0 = every change) has passed.
+        // g_verts / g_faces -> the device, as RayTracer.update does it (js/8-kd_tree.js:2458-2539): the vertex and face
+        // arrays go up on every frame (unless STATIC_GEOMETRY and done once), the tree and its root box are rebuilt only
+        // when none was built yet at a time other than 0 (`this.startTime == 0`) or at least KD_REBUILD_INTERVAL
+        // seconds (the reference's 0.30; 0 = every frame) have passed since the last build. In between the new
+        // vertices are rendered through the OLD tree and box (rt_update_vertices). Arrays that did not change are not
+        // sent again, and a rebuild from unchanged arrays is skipped (it would give the same tree).
         _updateGeometry(time) {
             if (!G.RENDER_TRIANGLES) return;
             if (G.STATIC_GEOMETRY && this.geometryUpdatedOnce) return;
             const interval = G.KD_REBUILD_INTERVAL === undefined ? 0.30 : G.KD_REBUILD_INTERVAL;
-            if (!(this.startTime === 0 || time - this.startTime >= interval) && this.geometryUpdatedOnce) return;
             const gv = G.g_verts, gf = G.g_faces;
             const verts = new Float64Array(gv.length * 3);
             for (let i = 0; i < gv.length; i++) { verts[3 * i] = gv[i].x; verts[3 * i + 1] = gv[i].y; verts[3 * i + 2] = gv[i].z; }
@@ -146,13 +148,24 @@ function makeRayTracer(G, THREE, api) {
             }
             const same = (a, b) => { if (!b || a.length !== b.length) return false; for (let i = 0; i < a.length; i++) if (a[i] !== b[i]) return false; return true; };
             const k = this._meshKey;
-            if (!(k && same(verts, k.verts) && same(faces, k.faces) && same(mats, k.mats))) {
+            const sameFaces = !!k && same(faces, k.faces) && same(mats, k.mats) && verts.length === k.verts.length;
+            const sameVerts = sameFaces && same(verts, k.verts);
+            const useTree = G.USE_KD_TREE && gf.length > 0;
+            const rebuildDue = useTree && (this.startTime == 0 || time - this.startTime >= interval);
+            const build = () => (G.KD_BUILDER === 'device' ? addon.buildKdTreeDevice : addon.buildKdTree)(this.ctx);
+            if (!sameFaces) {
+                // another face list: the old leaves would name other faces. (The reference would render exactly that
+                // until its next rebuild; its own UI never changes the face list after loading.)
                 addon.setMesh(this.ctx, verts, faces, mats);
-                // KD_BUILDER 'device': the same tree built on the GPU (rt_build_kdtree_device), for geometry that moves
-                if (G.USE_KD_TREE && gf.length > 0) (G.KD_BUILDER === 'device' ? addon.buildKdTreeDevice : addon.buildKdTree)(this.ctx);
-                this._meshKey = { verts, faces, mats };
+                if (useTree) { build(); this._treeVerts = verts; this.startTime = time; }
+            } else if (rebuildDue) {
+                if (!same(verts, this._treeVerts)) { addon.setMesh(this.ctx, verts, faces, mats); build(); this._treeVerts = verts; }
+                else if (!sameVerts) addon.updateVertices(this.ctx, verts);   // back where the tree was built
                 this.startTime = time;
+            } else if (!sameVerts) {
+                addon.updateVertices(this.ctx, verts);
             }
+            this._meshKey = { verts, faces, mats };
             this.geometryUpdatedOnce = true;
         }
 

@@ -257,3 +257,76 @@ def test_one_animated_frame_at_full_size_matches_the_oracle():
     st = rt.stats()
     assert st.rays_total == cn.rays and st.shadow_rays == cn.shadow_rays
     rt.close()
+
+
+@pytest.mark.parametrize("on_device", [False, True])
+def test_moved_vertices_under_the_old_tree_match_the_oracle(on_device):
+    """rt_update_vertices: new vertices through the tree and root box as they stand (what the reference renders between
+    two k-d rebuilds, js/8-kd_tree.js:2459-2533). The mesh is moved far enough that many faces leave the cells that list
+    them: the walk's pruning margin (rt_kdtree_overhang) must follow, and the frames - 640x480, depth 4, reflective and
+    transmissive mesh - must equal the oracle's for (moved vertices, old tree). A rebuild afterwards starts from the
+    moved vertices."""
+    import numpy as np
+    from oracle import oracle
+    flat = make_flat("bun_zipper_res4.ply", 640, 480, depth=4, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    rt = abi.RayTracerHIP(flat.cfg)
+    rt.setScene(flat, kd_on_device=on_device)
+    rt.trace()
+    kd0 = oracle.kd_build(flat.verts, np.asarray(flat.faces, np.uint32))
+    over0 = rt.kdOverhang()
+    v0 = np.asarray(flat.verts, np.float64)
+    rng = np.random.default_rng(5)
+    for k, shift in enumerate(((1.5, 0.75, -1.0), (9.0, -4.0, 6.0), (-20.0, 3.0, 2.0))):
+        # a translation plus a little noise per vertex: no two frames share a vertex array
+        v = v0 + np.array(shift) + rng.uniform(-0.05, 0.05, v0.shape)
+        rt.updateVertices(v)
+        rt.trace()
+        over = rt.kdOverhang()
+        assert over.max() > over0.max()
+        flat.verts = v
+        o = oracle.OracleRenderer(flat, kd=kd0)
+        want_f, want_8, want_id, cn = o.trace(threads=16)
+        assert np.array_equal(rt.readHitIds(), want_id), k
+        assert np.array_equal(rt.readRGBA8(), want_8), k
+        got_f = rt.readFloat()
+        assert ((got_f == want_f) | (np.isnan(got_f) & np.isnan(want_f))).all(), k
+        assert rt.stats().rays_total == cn.rays
+    # the next rebuild uses the moved vertices
+    rt.buildKdTree(on_device=on_device)
+    rt.trace()
+    want = oracle.OracleRenderer(flat).trace(threads=16)
+    assert np.array_equal(rt.readRGBA8(), want[1]) and np.array_equal(rt.readHitIds(), want[2])
+    pairs, leaves, box = rt.exportKdTree()
+    kd1 = oracle.kd_build(flat.verts, np.asarray(flat.faces, np.uint32))
+    assert np.array_equal(pairs, kd1[0]) and np.array_equal(leaves, kd1[1]) and np.array_equal(box, kd1[2])
+    rt.close()
+
+
+def test_update_vertices_leaves_the_other_holders_of_a_shared_tree_alone():
+    """Two contexts with the same scene share one device copy of the tree; moving the vertices of one must not move the
+    other's."""
+    import numpy as np
+    flat = make_flat("bun_zipper_res4.ply", 320, 240, depth=2)
+    a, b = abi.RayTracerHIP(flat.cfg), abi.RayTracerHIP(flat.cfg)
+    a.setScene(flat)
+    b.setScene(flat)
+    a.trace()
+    b.trace()
+    before = b.readRGBA8()
+    assert np.array_equal(a.readRGBA8(), before)
+    a.updateVertices(np.asarray(flat.verts, np.float64) + np.array([12.0, 5.0, -3.0]))
+    a.trace()
+    b.trace()
+    assert np.array_equal(b.readRGBA8(), before)
+    assert not np.array_equal(a.readRGBA8(), before)
+    a.close()
+    b.close()
+
+
+def test_update_vertices_refuses_another_vertex_count():
+    flat = make_flat("bun_zipper_res4.ply", 64, 48)
+    rt = abi.RayTracerHIP(flat.cfg)
+    rt.setScene(flat)
+    with pytest.raises(abi.RTError, match="another number of vertices"):
+        rt.updateVertices(np.zeros((5, 3)))
+    rt.close()

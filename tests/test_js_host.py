@@ -275,3 +275,74 @@ def test_js_drag_the_mesh_and_render_equals_oracle():
     assert np.array_equal(rt.readRGBA8(), want_8) and np.array_equal(rt.readHitIds(), want_id)
     assert out["drag_rgba8_sha256"] != out["rgba8_sha256"]      # the frame did change
     rt.close()
+
+
+def _drag_sequence(times, step, width=320, height=240, depth=3, mm=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9)):
+    """What the reference renders for a mesh moved by `step` before every frame but the first: per frame the flattened
+    scene with the moved vertices and the index of the frame whose vertices the tree in use was built from - rebuilt
+    when `startTime == 0` or 0.30 s have passed, js/8-kd_tree.js:2494-2522. The mesh moves through the Python twin of
+    Mesh.translate (float32 matrix round trip, js/8-kd_tree.js:2055-2064)."""
+    from ray_tracer_amd import abi, scene
+    from ray_tracer_amd.three_f32 import Vector3
+    from helpers import model
+    sc = scene.default_scene(model("bun_zipper_res4.ply"), mesh_material=mm)
+    mesh = sc.objects[-1]
+    out, start, tree_of = [], 0.0, None
+    for k, t in enumerate(times):
+        if k > 0:
+            mesh.translate(Vector3(*step))
+        scene.animate_light(sc, t)
+        flat = abi.FlatScene(sc, abi.default_config(width, height, depth=depth), scene.camera_rays(width, height))
+        if tree_of is None or start == 0 or t - start >= 0.30:
+            tree_of, start = k, t
+        out.append((flat, tree_of))
+    return out
+
+
+@needs_node
+@pytest.mark.gpu
+@pytest.mark.parametrize("builder", ["host", "device"])
+def test_js_moving_mesh_renders_new_vertices_through_the_old_tree_like_the_reference(builder):
+    """A mesh dragged on three frames inside one rebuild interval, then a frame after the interval, from JavaScript.
+    Every frame must equal the oracle's render of (moved vertices, the tree and root box of the last rebuild) - the
+    reference uploads the vertices on every frame and the tree at most every 0.30 s."""
+    from oracle import oracle
+    times = [1.0, 1.0 + 1 / 60, 1.0 + 2 / 60, 1.0 + 3 / 60, 1.31]
+    step = (1.5, 0.75, -1.0)
+    out = run_node([os.path.join(JS, "examples", "drag_frames.js"), "--times", ",".join(repr(t) for t in times),
+                    "--step", ",".join(str(v) for v in step), "--kd-builder", builder, "--mesh-material", "0.7,0.6,0.7,16,0.3,0.5,0.9"])
+    seq = _drag_sequence(times, step)
+    assert [tree for _, tree in seq] == [0, 0, 0, 0, 4]
+    kds = {}
+    seen = set()
+    for k, ((flat, tree), fr) in enumerate(zip(seq, out["frames"])):
+        assert fr["verts_sha256"] == hashlib.sha256(np.ascontiguousarray(flat.verts, np.float64).tobytes()).hexdigest(), k
+        if tree not in kds:
+            kds[tree] = oracle.kd_build(seq[tree][0].verts, np.asarray(seq[tree][0].faces, np.uint32))
+        assert fr["kd_box"] == list(kds[tree][2]), k
+        want_8 = oracle.OracleRenderer(flat, kd=kds[tree]).trace(threads=16)[1]
+        assert fr["rgba8_sha256"] == hashlib.sha256(np.ascontiguousarray(want_8).tobytes()).hexdigest(), k
+        seen.add(fr["rgba8_sha256"])
+    assert len(seen) == len(times)   # every frame differs from the others
+    # and a stale tree is visible: frame 3 rendered through its own fresh tree is another image
+    fresh = oracle.OracleRenderer(seq[3][0]).trace(threads=16)[1]
+    assert hashlib.sha256(np.ascontiguousarray(fresh).tobytes()).hexdigest() != out["frames"][3]["rgba8_sha256"]
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_tree_is_rebuilt_on_every_frame_while_start_time_is_zero():
+    """`this.startTime == 0` (js/8-kd_tree.js:2495): a first frame at time 0 leaves startTime at 0, so the second frame
+    rebuilds as well; from then on the interval counts."""
+    from oracle import oracle
+    times = [0.0, 1 / 60, 2 / 60]
+    step = (-2.0, 1.0, 0.5)
+    out = run_node([os.path.join(JS, "examples", "drag_frames.js"), "--times", ",".join(repr(t) for t in times),
+                    "--step", ",".join(str(v) for v in step), "--width", "160", "--height", "120",
+                    "--mesh-material", "0.7,0.6,0.7,16,0.3,0.5,0.9"])
+    seq = _drag_sequence(times, step, 160, 120)
+    assert [tree for _, tree in seq] == [0, 1, 1]
+    for k, ((flat, tree), fr) in enumerate(zip(seq, out["frames"])):
+        kd = oracle.kd_build(seq[tree][0].verts, np.asarray(seq[tree][0].faces, np.uint32))
+        want_8 = oracle.OracleRenderer(flat, kd=kd).trace(threads=16)[1]
+        assert fr["rgba8_sha256"] == hashlib.sha256(np.ascontiguousarray(want_8).tobytes()).hexdigest(), k
