@@ -216,6 +216,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = comm.max_float(dt)
+    if hasattr(frame, "close"):
+        frame.close()   # (events and views of the contexts' streams go before the contexts do)
     # per-kernel times: device events of the library around every launch, taken from frames traced one at a time after
     # the timed region (with several frames in flight the kernels of different frames share the GPU)
     n_detail = min(args.steps, 5)
@@ -294,6 +296,13 @@ def main():
         "trace_only_ms": trace_ms, "composite_ms": comp_ms, "tone_ms": tone_ms,
         "frames_in_flight": n_ctx, "frame_job": "pipelined (stream-ordered, device-resident exchange)" if pipelined else "host-synchronised",
         "frames_retraced": getattr(frame, "redone", 0),
+        # what the collectives saw: the backend, how many ranks the process group of the first device collective held, and
+        # the mean host time per frame of completing a frame (rt_trace_end, which waits for the device, + reading the
+        # all-reduced overflow flag: finish_flag_ms is that second part alone)
+        "backend": (args.backend if world > 1 else None),
+        "world_size_joined": (getattr(frame, "joined", None) or (comm.dist.get_world_size() if comm.dist else 1)),
+        "finish_host_ms": (frame.finish_s / frame.finished * 1e3) if getattr(frame, "finished", 0) else None,   # mostly the wait for the device (frames in flight)
+        "finish_flag_ms": (frame.flag_s / frame.finished * 1e3) if getattr(frame, "finished", 0) else None,
         "step_kernel_ms": [round(float(x), 4) for x in lvl_ms[:args.depth + 1]],
         "stage_names": ["k_gen_prims", "k_kd_walk", "k_shade_b", "k_shade_a"],
         "pipeline_step": "step k = k_gen_prims(level k), k_kd_walk (closest-hit rays of level k with the shadow rays of level k-1, triangle tests inside the walk), k_shade_b(level k-1), k_shade_a(level k)",

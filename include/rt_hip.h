@@ -225,10 +225,13 @@ int rt_tone(rt_ctx *ctx, double *Lbar, double *sf);
  * memory (rt_device_canvas) */
 int rt_present(rt_ctx *ctx, uint8_t *canvas_rgba);
 /* The same reduction with nothing returning to the host, for multi-GPU callers that all-reduce on the device:
- * rt_tone_partial_device queues the reduction and hands out the device address of two doubles,
- * {sum of log(EPSILON + L), pixel count}; the caller sums them over the ranks in place (on the context's stream, see
- * rt_stream) and passes the address to rt_tone_finish_device, which queues the Lbar / sf computation; rt_present then
- * uses them. rt_tone_get waits and returns the Lbar / sf last computed by either path. Device exp/pow may differ from
+ * rt_tone_partial_device queues the reduction and hands out the device address of THREE doubles,
+ * {sum of log(EPSILON + L), pixel count, 1.0 if the last trace ran out of buffer space and rt_trace_end will repeat it,
+ * else 0.0}; the caller sums them over the ranks in place (on the context's stream, see rt_stream) and passes the
+ * address to rt_tone_finish_device, which queues the Lbar / sf computation from the first two; rt_present then uses
+ * them. The third sum tells every rank alike - from its own device memory, without a host-side collective - whether
+ * any rank's contribution to this frame was void, i.e. whether the exchange of the frame must be repeated once
+ * rt_trace_end has returned. rt_tone_get waits and returns the Lbar / sf last computed by either path. Device exp/pow may differ from
  * the host's in the last bit of the double; the present pass receives them rounded to float, as in the reference. */
 int rt_tone_partial_device(rt_ctx *ctx, void **d_sum_count);
 int rt_tone_finish_device(rt_ctx *ctx, const void *d_sum_count);

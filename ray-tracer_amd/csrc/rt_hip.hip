@@ -167,7 +167,7 @@ struct rt_ctx {
     uint32_t *d_compact_canvas = nullptr;        // rt_present_shard: the shard's tiles after the present pass
     int32_t *d_hit = nullptr;
     double *d_part_sum = nullptr, *d_tone_out = nullptr;
-    double *d_tone_pair = nullptr;               // {sum of log luminance, pixel count} of this shard, for a device-side all-reduce
+    double *d_tone_pair = nullptr;               // {sum of log luminance, pixel count, 1.0 if the trace overflowed a buffer} of this shard, for a device-side all-reduce
     float *d_tone = nullptr;                     // Lbar, sf as the present pass reads them
     double *d_tone_d = nullptr;                  // the same in double precision
     bool tone_on_device = false;                 // Lbar / sf were computed by rt_tone_finish_device: the host copy is stale
@@ -761,7 +761,7 @@ int rt_create(const rt_config *cfg, rt_ctx **out) {
     ALLOC(ctx->d_part_cnt, TONE_BLOCKS * sizeof(unsigned long long));
     ALLOC(ctx->d_tone_out, sizeof(double));
     ALLOC(ctx->d_tone_cnt, sizeof(unsigned long long));
-    ALLOC(ctx->d_tone_pair, 2 * sizeof(double));
+    ALLOC(ctx->d_tone_pair, 3 * sizeof(double));
     ALLOC(ctx->d_tone, 2 * sizeof(float));
     ALLOC(ctx->d_tone_d, 2 * sizeof(double));
 #undef ALLOC
@@ -1313,6 +1313,17 @@ static int queue_tone_reduction(rt_ctx *ctx) {
                        ctx->d_part_sum, ctx->d_part_cnt);
     hipLaunchKernelGGL(k_tone_final, dim3(1), dim3(64), 0, s, ctx->d_part_sum, ctx->d_part_cnt, blocks, ctx->d_tone_out,
                        ctx->d_tone_cnt, ctx->d_tone_pair);
+    {
+        static_assert(MAX_PARTS <= 8, "OverflowArgs holds eight parts");
+        OverflowArgs oa{};
+        oa.n_parts = ctx->n_parts;
+        oa.depth = ctx->cfg.max_depth;
+        for (int p = 0; p < ctx->n_parts; p++) {
+            oa.cnt[p] = ctx->parts[p].d_counts;
+            for (int l = 0; l < MAX_LEVELS; l++) oa.cap[p][l] = ctx->parts[p].lv[l].cap;
+        }
+        hipLaunchKernelGGL(k_overflow_flag, dim3(1), dim3(1), 0, s, oa, ctx->d_tone_pair + 2);
+    }
     HIPCK(hipGetLastError());
     HIPCK(hipEventRecord(ctx->ev_misc[1], s));
     return 0;

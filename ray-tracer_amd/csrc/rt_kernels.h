@@ -1163,6 +1163,21 @@ __global__ __launch_bounds__(64) void k_tone_final(const double *part_sum, const
     }
 }
 
+// 1.0 when a ray-tree level of this context's last trace produced more children than the next level's buffer holds
+// (rt_trace_end will trace that frame again), else 0.0: the third number of the exchange, so that after the all-reduce
+// every rank knows whether ANY rank's sums and tiles of this frame are void.
+struct OverflowArgs {
+    const LevelCounters *cnt[8];   // per part
+    uint32_t cap[8][MAX_LEVELS];   // capacity of every level of the part
+    int32_t n_parts, depth;
+};
+__global__ void k_overflow_flag(OverflowArgs a, double *flag) {
+    bool over = false;
+    for (int p = 0; p < a.n_parts; p++)
+        for (int l = 0; l + 1 < a.depth; l++) over = over || a.cnt[p][l].next_count > a.cap[p][l + 1];
+    *flag = over ? 1.0 : 0.0;
+}
+
 // Lbar = exp(sum / N); sf = ((1.219 + (Ldmax/2)^0.4) / (1.219 + Lbar^0.4))^2.5  (js/8-kd_tree.js:2568-2569), from sums that
 // stayed in device memory. tone[0..1] = Lbar, sf as the float uniforms the present shader receives (js/8-kd_tree.js:2579-2581),
 // tone_d the same in double precision.

@@ -211,18 +211,22 @@ class PipelinedFrameJob:
     """The same frame as FrameJob, queued without host synchronisation and with several frames in flight.
 
     Every context (one per frame in flight) owns a HIP stream; the trace, the luminance reduction, the RCCL all-reduce
-    of the two sums (in place, in the library's device memory), the tile gather, the assemble, the tone finish and the
-    present pass of a frame are all queued on that stream, so the device orders them and the host only waits - one
-    step later - for the trace's buffer check (rt_trace_end). While the exchange of frame i runs, the kernels of frame
-    i+1 (another context, another stream) fill the GPU. Needs device-side collectives: backend "nccl", or one rank."""
+    of three doubles (in place, in the library's device memory: the two luminance sums and a flag the trace raises on
+    the device when it ran out of buffer space), the tile gather, the assemble, the tone finish and the present pass of a
+    frame are all queued on that stream, so the device orders them and the host only waits - when it reuses the context
+    some frames later - for the trace's buffer check (rt_trace_end) and for its copy of the reduced flag: every rank
+    reads the same number there, so all ranks repeat the exchange of a frame that any rank had to trace again, and no
+    host-side collective is on the per-frame path. While the exchange of frame i runs, the kernels of frame i+1
+    (another context, another stream) fill the GPU. backend "nccl": collectives on device memory over RCCL; backend
+    "gloo": rehearsal, the three doubles and the tiles are staged through the host (several ranks may share a GPU)."""
 
     def __init__(self, rts, comm, present="auto", rehearse=None):
         """rehearse = (role, n_shards), single rank only: the contexts are shards of an n_shards-way split and every
         frame does the device work of one rank of such a job without the collectives - "worker": trace, sums, present
         of the own tiles; "root": also the scatter of n_shards gathered canvas buffers (whatever they hold)."""
         import torch
-        assert comm.dist is None or comm.backend == "nccl", "the pipelined job needs RCCL (or a single rank)"
         self.torch, self.comm = torch, comm
+        self.staged = comm.dist is not None and comm.backend != "nccl"
         able = all(rt.cfg.supersampling == 1 for rt in rts)
         assert present in ("auto", "root", "shards") and (present != "shards" or able)
         self.by_shards = (able if present == "auto" else present == "shards") and comm.dist is not None   # see FrameJob
@@ -235,9 +239,14 @@ class PipelinedFrameJob:
                         if comm.rank == 0 and comm.dist is not None else None)
             if self.rehearse and self.rehearse[0] == "root":
                 gathered = torch.zeros(self.rehearse[1] * sh.stride, dtype=torch.uint8, device=comm.device)
-            self.slots.append({"rt": rt, "shard": sh, "stream": st, "gathered": gathered, "busy": False, "pair": None})
+            self.slots.append({"rt": rt, "shard": sh, "stream": st, "gathered": gathered, "busy": False, "pair": None,
+                               "pair_host": torch.zeros(3, dtype=torch.float64).pin_memory(), "ev": torch.cuda.Event()})
         self.i = 0
         self.redone = 0
+        self.finish_s = 0.0    # host time spent completing frames (waiting in rt_trace_end for the device + the reduced flag), and how many
+        self.flag_s = 0.0      # of that: waiting for and reading the all-reduced overflow flag (after rt_trace_end returned)
+        self.finished = 0
+        self.joined = None     # ranks that took part in the first device collective
         self.rays = 0          # rays of all completed frames (this rank's shard)
         self.shadow_rays = 0
 
@@ -246,7 +255,7 @@ class PipelinedFrameJob:
         rt, sh, comm, torch = slot["rt"], slot["shard"], self.comm, self.torch
         dptr = rt.tonePartialDevice()
         if slot["pair"] is None:
-            slot["pair"] = torch.as_tensor(_DevView64(dptr, 2), device=comm.device)
+            slot["pair"] = torch.as_tensor(_DevView64(dptr, 3), device=comm.device)
         if self.rehearse:
             rt.toneFinishDevice(dptr)
             rt.presentShard()
@@ -256,21 +265,19 @@ class PipelinedFrameJob:
                        "rt_assemble_shards_canvas")
             return
         if self.by_shards:
-            comm.dist.all_reduce(slot["pair"])
+            self._allreduce(slot)
             rt.toneFinishDevice(dptr)
             rt.presentShard()
             buf, stride = sh.shard_canvas_bytes()
-            parts = list(slot["gathered"].split(stride)) if comm.rank == 0 else None
-            comm.dist.gather(buf, gather_list=parts, dst=0)
+            self._gather(slot, buf, stride)
             if comm.rank == 0:
                 rt._ck(rt.L.rt_assemble_shards_canvas(rt.ctx, C.c_void_p(slot["gathered"].data_ptr()), C.c_size_t(stride), comm.world),
                        "rt_assemble_shards_canvas")
             return
         if comm.dist is not None:
-            comm.dist.all_reduce(slot["pair"])
+            self._allreduce(slot)
             buf, stride = sh.shard_bytes()
-            parts = list(slot["gathered"].split(stride)) if comm.rank == 0 else None
-            comm.dist.gather(buf, gather_list=parts, dst=0)
+            self._gather(slot, buf, stride)
             if comm.rank == 0:
                 rt._ck(rt.L.rt_assemble_shards(rt.ctx, C.c_void_p(slot["gathered"].data_ptr()), C.c_size_t(stride), comm.world),
                        "rt_assemble_shards")
@@ -278,13 +285,50 @@ class PipelinedFrameJob:
         if comm.rank == 0:
             rt.presentQueued()
 
+    def _allreduce(self, slot):
+        """{sum of log luminance, pixel count, overflow flag} summed over the ranks in place, on the slot's stream; a
+        copy of the result goes to page-locked host memory behind it (read by _finish when the context is reused)."""
+        comm, pair = self.comm, slot["pair"]
+        if self.staged:
+            t = pair.cpu()                      # (waits for the slot's stream)
+            comm.dist.all_reduce(t)
+            pair.copy_(t)
+        else:
+            comm.dist.all_reduce(pair)
+        if self.joined is None:
+            self.joined = comm.dist.get_world_size()
+        slot["pair_host"].copy_(pair, non_blocking=True)
+        slot["ev"].record()
+
+    def _gather(self, slot, buf, stride):
+        comm = self.comm
+        if self.staged:
+            g = comm.gather_bytes(buf, stride)
+            if comm.rank == 0:
+                slot["gathered"].copy_(g)
+            return
+        parts = list(slot["gathered"].split(stride)) if comm.rank == 0 else None
+        comm.dist.gather(buf, gather_list=parts, dst=0)
+
     def _finish(self, slot):
         if not slot["busy"]:
             return
         slot["busy"] = False
+        import time
+        t0 = time.perf_counter()
         # every rank must take the same decision: a rank whose buffers overflowed traced again, and the sums and
-        # tiles it sent were wrong, so all ranks repeat the exchange of that frame
-        redo = self.comm.any_flag(slot["rt"].traceEnd())
+        # tiles it sent were void, so all ranks repeat the exchange of that frame. The decision comes out of the
+        # exchange itself: the third all-reduced number counts the ranks whose trace overflowed
+        redo = slot["rt"].traceEnd()
+        if self.comm.dist is not None:
+            t1 = time.perf_counter()
+            slot["ev"].synchronize()
+            anyone = float(slot["pair_host"][2]) > 0.0
+            assert anyone or not redo, "a trace that was repeated must have raised its flag in the exchange"
+            redo = anyone
+            self.flag_s += time.perf_counter() - t1
+        self.finish_s += time.perf_counter() - t0
+        self.finished += 1
         if redo:
             self.redone += 1
             with self.torch.cuda.stream(slot["stream"]):
@@ -315,6 +359,27 @@ class PipelinedFrameJob:
     def flush(self):
         for k in range(len(self.slots)):
             self._finish(self.slots[(self.i + k) % len(self.slots)])
+
+    def close(self):
+        """Completes what is queued and lets go of the torch objects that refer to the contexts' streams and memory
+        (events, views); call it before the contexts are destroyed."""
+        self.flush()
+        self.torch.cuda.synchronize()
+        self._release()
+
+    def _release(self):
+        # events first, contexts (whose streams the events were recorded on) last
+        for slot in self.slots:
+            for k in ("ev", "pair_host", "pair", "gathered", "stream", "shard"):
+                slot[k] = None
+        self.slots = []
+
+    def __del__(self):
+        try:
+            self.torch.cuda.synchronize()
+            self._release()
+        except Exception:   # noqa: BLE001 (interpreter shutdown)
+            pass
 
     def tone(self, k=-1):
         """Lbar, sf of the frame last completed on context k (waits for its stream)."""

@@ -534,6 +534,26 @@ def test_pipelined_job_with_device_collectives_one_rank():
                 gl, gs = rt.toneGet()
                 assert abs(gl - wl) <= 1e-12 * wl and np.float32(gs) == np.float32(ws)
                 assert np.array_equal(device_canvas(rt), want_canvas), mode
+            assert job.redone == 0 and job.joined == 1 and job.finished == 4
+        # contexts whose buffers are far too small for their first frame: the trace raises its flag on the device, the
+        # flag travels through the all-reduce, and the exchange of those frames is repeated (no host-side collective)
+        small = []
+        for _ in range(2):
+            rt = abi.RayTracerHIP(flat.cfg)
+            rt.setScene(flat)
+            rt.setOption("first_level_rays", 256)
+            small.append(rt)
+        job = multi_gpu.PipelinedFrameJob(small, comm, present="shards")
+        for _ in range(4):
+            job.step()
+        job.flush()
+        torch.cuda.synchronize()
+        assert job.redone == 2
+        job.close()
+        for rt in small:
+            assert np.array_equal(rt.readRGBA8(), ref.readRGBA8())
+            assert np.array_equal(device_canvas(rt), want_canvas)
+            rt.close()
     finally:
         comm.close()
 

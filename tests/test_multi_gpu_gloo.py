@@ -207,6 +207,78 @@ def test_two_hip_shards_equal_one_context():
     rt.close()
 
 
+def pipelined_worker(rank, world, port, out):
+    """The stream-ordered job over gloo (the exchange staged through the host), all ranks on GPU 0. The buffers of the
+    LAST rank only are far too small for its first frames: its trace raises the overflow flag on the device, the flag is
+    all-reduced with the luminance sums, and every rank - reading the same number from its own copy - repeats the
+    exchange of exactly those frames."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import faulthandler
+    import hashlib
+    faulthandler.enable()
+    from ray_tracer_amd import abi, multi_gpu
+    torch.cuda.set_device(0)
+    flat = make_flat("bun_zipper_res4.ply", 324, 243, depth=3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9),
+                     shard_index=rank, shard_count=world)
+    rts = []
+    for _ in range(2):
+        rt = abi.RayTracerHIP(flat.cfg)
+        rt.setScene(flat)
+        if rank == world - 1:
+            rt.setOption("first_level_rays", 256)
+        rts.append(rt)
+    comm = multi_gpu.Comm(rank, world, 0, backend="gloo", device="cuda:0")
+    job = multi_gpu.PipelinedFrameJob(rts, comm)
+    assert job.by_shards and job.staged
+    for _ in range(5):
+        job.step()
+    job.flush()
+    torch.cuda.synchronize()
+    res = {"rank": rank, "redone": job.redone, "joined": job.joined, "finished": job.finished, "tone": [rt.toneGet() for rt in rts]}
+    if rank == 0:
+        res["canvas"] = []
+        for rt in rts:
+            p, n = abi.C.c_void_p(), abi.C.c_size_t()
+            rt._ck(rt.L.rt_device_canvas(rt.ctx, abi.C.byref(p), abi.C.byref(n)), "rt_device_canvas")
+            canvas = torch.as_tensor(multi_gpu._DevView(p.value, n.value), device="cuda:0").cpu().numpy()
+            res["canvas"].append(hashlib.sha256(canvas.tobytes()).hexdigest())
+    out.put(res)
+    job.close()
+    comm.close()
+    for rt in rts:
+        rt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_job_over_gloo_repeats_a_frame_that_one_rank_retraced(world):
+    import hashlib
+    from ray_tracer_amd import abi
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=pipelined_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r["rank"]: r for r in (q.get(timeout=240) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    flat = make_flat("bun_zipper_res4.ply", 324, 243, depth=3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    rt = abi.RayTracerHIP(flat.cfg)
+    rt.setScene(flat)
+    rt.trace()
+    Lbar, sf = rt.tone()
+    want = hashlib.sha256(np.ascontiguousarray(rt.present()).tobytes()).hexdigest()
+    assert results[0]["canvas"] == [want, want]
+    for r in results.values():
+        # both contexts of the last rank were too small on their first frame: every rank repeated those two exchanges
+        assert r["redone"] == 2 and r["joined"] == world and r["finished"] == 5
+        for gl, gs in r["tone"]:
+            assert abs(gl - Lbar) <= 1e-10 * Lbar and np.float32(gs) == np.float32(sf)
+    rt.close()
+
+
 def _run_bench(args, timeout=600):
     import json
     import subprocess
