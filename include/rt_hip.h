@@ -119,6 +119,7 @@ typedef struct rt_stats {
     double   tone_ms;           /* device time of the last rt_tone reduction */
     double   kd_build_ms;       /* host time of the last rt_build_kdtree */
     double   kd_upload_ms;      /* host->device copy of the compact tree */
+    uint64_t kd_device_fallbacks; /* rt_build_kdtree_device calls of this context that stalled on the device and built on the host instead */
 } rt_stats;
 
 /* ---- life cycle ------------------------------------------------------------------ */
@@ -167,7 +168,10 @@ int rt_update_vertices(rt_ctx *ctx, const double *verts, int32_t n_verts);
 int rt_build_kdtree(rt_ctx *ctx);
 /* The same tree, bit for bit, built level by level on the GPU and left in device memory: for geometry that changes
  * every frame (the reference rebuilds while objects are dragged, js/8-kd_tree.js:2494-2522). Only vertices, faces and
- * material slots cross PCIe. rt_kdtree_counts / rt_export_kdtree_reference work on it like on the host-built tree. */
+ * material slots cross PCIe. rt_kdtree_counts / rt_export_kdtree_reference work on it like on the host-built tree.
+ * Should the device build stall (its in-kernel sums wait for workgroups with a lower index, see kd_build_gpu.hip; the
+ * wait is bounded, environment RT_KD_CHAIN_POLL_LIMIT), the call prints a warning, builds the same tree with
+ * rt_build_kdtree and counts the event in rt_stats.kd_device_fallbacks. */
 int rt_build_kdtree_device(rt_ctx *ctx);
 /* sizes of the canonical (reference-layout) export */
 int rt_kdtree_counts(rt_ctx *ctx, int64_t *n_nodes, int64_t *n_leaves);

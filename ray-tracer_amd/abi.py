@@ -46,7 +46,7 @@ class Stats(C.Structure):
                 ("level_stage_ms", (C.c_double * 7) * 8), ("stage_ms", C.c_double * 7), ("tri_records", C.c_uint64 * 2),
                 ("kd_closest_rays", C.c_uint64), ("kd_shadow_rays", C.c_uint64),
                 ("composite_ms", C.c_double), ("tone_ms", C.c_double), ("kd_build_ms", C.c_double),
-                ("kd_upload_ms", C.c_double)]
+                ("kd_upload_ms", C.c_double), ("kd_device_fallbacks", C.c_uint64)]
 
 
 def default_config(width=640, height=480, depth=1, supersampling=1, **kw):

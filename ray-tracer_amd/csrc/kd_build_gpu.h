@@ -51,6 +51,7 @@ public:
 
     GpuKdTree tree;
     int predicted_misses = 0;       // builds whose predicted sizes did not hold and that were repeated level by level
+    bool stalled = false;           // the last build failed because a workgroup's wait ran out (see chained_ranks)
 
 private:
     struct LevelNodes {
@@ -95,6 +96,7 @@ private:
     uint32_t *chain = nullptr;                               // states of the sums computed inside k_kd_test / k_kd_emit
     size_t cap_chain = 0;
     uint32_t chain_flat = 0;                                 // launches of up to this many workgroups sum in one step
+    uint32_t poll_limit = 0;                                 // polls after which a workgroup stops waiting for another's count
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     uint32_t cap_node_slots = 0, cap_slots = 0, cap_tris = 0, cap_leaf_table = 0;

@@ -125,18 +125,20 @@ __global__ __launch_bounds__(256) void k_kd_setup(const double *verts, const uin
 // before it looks at the groups in front, and a workgroup adds the own counts in front of it in its group (one per
 // lane) and the totals of the groups in front of that. Either way there is no chain of dependent hand-overs: a value
 // takes about as long from one workgroup to another as a small kernel takes in all.
-// A workgroup only ever waits for workgroups with a lower index: those are dispatched before it, so they are running or
-// done. A wait that lasts longer than any launch could (seconds) gives up and says so in *stall: the build is then
-// reported as failed, and no wave ever waits without end.
+// A workgroup only ever waits for workgroups with a lower index. That those are running or done when it looks leans on
+// the order in which the hardware starts workgroups (ascending index, round the XCDs); HIP does not promise that
+// order. So a wait that lasts longer than any launch could (poll_limit polls, seconds by default) gives up and says so
+// in *stall: no wave ever waits without end, the build is reported as stalled, and the caller falls back to the host
+// builder (rt_build_kdtree_device).
 constexpr uint32_t CHAIN_VALID = 0x80000000u;
-constexpr uint32_t CHAIN_POLL_LIMIT = 1u << 22;   // several seconds: kernels of other streams may hold back a workgroup for a while
+constexpr uint32_t CHAIN_POLL_LIMIT = 1u << 22;   // default of GpuKdBuilder::poll_limit, several seconds: kernels of other streams may hold back a workgroup for a while
 constexpr uint32_t CHAIN_FLAT = 2048;
 constexpr int CHAIN_SHARED_WORDS_PER_FLAG = 12;
 
-__device__ __forceinline__ uint32_t chain_wait(const uint32_t *word, uint32_t *stall) {
+__device__ __forceinline__ uint32_t chain_wait(const uint32_t *word, uint32_t *stall, uint32_t poll_limit) {
     uint32_t v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (uint32_t polls = 0; !(v & CHAIN_VALID); polls++) {
-        if (polls > CHAIN_POLL_LIMIT) { *stall = 1u; break; }
+        if (polls >= poll_limit) { *stall = 1u; break; }
         __builtin_amdgcn_s_sleep(1);
         v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -160,7 +162,7 @@ __device__ __forceinline__ void chain_block_sums(uint32_t (&x)[K], uint32_t *slo
 // launch; upto[k] = the same including the whole workgroup. sh: K * CHAIN_SHARED_WORDS_PER_FLAG words.
 template <int K>
 __device__ __forceinline__ void chained_ranks(uint32_t *chain, uint32_t tile, uint32_t tiles, uint32_t flat_limit, const bool (&flag)[K],
-                                              uint32_t *sh, uint32_t *stall, uint32_t (&rank)[K], uint32_t (&upto)[K]) {
+                                              uint32_t *sh, uint32_t *stall, uint32_t poll_limit, uint32_t (&rank)[K], uint32_t (&upto)[K]) {
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t stride = tiles + ((tiles + 255u) >> 8);   // words per flag: own counts, then group totals
     uint32_t own[K], part[K];
@@ -172,11 +174,11 @@ __device__ __forceinline__ void chained_ranks(uint32_t *chain, uint32_t tile, ui
     for (int k = 0; k < K; k++) part[k] = 0u;
     if (tiles <= flat_limit) {
         for (uint32_t i = threadIdx.x; i < tile; i += 256u)
-            for (int k = 0; k < K; k++) part[k] += chain_wait(chain + k * stride + i, stall);
+            for (int k = 0; k < K; k++) part[k] += chain_wait(chain + k * stride + i, stall, poll_limit);
     } else {
         const uint32_t group = tile >> 8, first = group << 8;
         if (first + threadIdx.x < tile)
-            for (int k = 0; k < K; k++) part[k] = chain_wait(chain + k * stride + first + threadIdx.x, stall);
+            for (int k = 0; k < K; k++) part[k] = chain_wait(chain + k * stride + first + threadIdx.x, stall, poll_limit);
         if ((tile & 255u) == 255u) {   // the last of its group: the group's totals must not wait for the groups in front
             uint32_t in_group[K];
             for (int k = 0; k < K; k++) in_group[k] = part[k];
@@ -187,7 +189,7 @@ __device__ __forceinline__ void chained_ranks(uint32_t *chain, uint32_t tile, ui
                                        __HIP_MEMORY_SCOPE_AGENT);
         }
         for (uint32_t g = threadIdx.x; g < group; g += 256u)
-            for (int k = 0; k < K; k++) part[k] += chain_wait(chain + k * stride + tiles + g, stall);
+            for (int k = 0; k < K; k++) part[k] += chain_wait(chain + k * stride + tiles + g, stall, poll_limit);
     }
     chain_block_sums<K>(part, sh + 8 * K);
     for (int k = 0; k < K; k++) {
@@ -213,7 +215,7 @@ __device__ __forceinline__ uint32_t owner_of(const uint32_t *pool_owner, const u
 __global__ __launch_bounds__(256) void k_kd_test(const double *verts, const uint32_t *faces, const uint32_t *pool_face,
                                                  const uint32_t *pool_owner, const uint32_t *owner_map, const uint32_t *st,
                                                  uint32_t bound, Nodes cur, int axis, uint32_t *flags, uint2 *scanned,
-                                                 uint32_t *chain, uint32_t flat_limit, uint32_t *stall) {
+                                                 uint32_t *chain, uint32_t flat_limit, uint32_t *stall, uint32_t poll_limit) {
     __shared__ uint32_t sh[2 * CHAIN_SHARED_WORDS_PER_FLAG];
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     const bool in_grid = p < bound;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void k_kd_test(const double *verts, const uint
         flags[p] = (into[0] ? 1u : 0u) | (into[1] ? 2u : 0u);
     }
     uint32_t rank[2], upto[2];
-    chained_ranks<2>(chain, blockIdx.x, gridDim.x, flat_limit, into, sh, stall, rank, upto);
+    chained_ranks<2>(chain, blockIdx.x, gridDim.x, flat_limit, into, sh, stall, poll_limit, rank, upto);
     if (in_grid) scanned[p] = make_uint2(rank[0], rank[1]);
     if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0u) scanned[bound] = make_uint2(upto[0], upto[1]);
 }
@@ -342,7 +344,7 @@ __device__ __forceinline__ void kd_scatter(uint32_t block, const LevelIn &in, co
 // One lane per child: size of its list -> splits again / leaf / empty leaf; node records in the treelet layout, boxes of
 // the next level, leaves to a list. tile = number of the workgroup among the `tiles` that do this.
 __device__ __forceinline__ void kd_emit(uint32_t tile, uint32_t tiles, const LevelIn &in, const Nodes &cur, const Nodes &nxt, const LevelOut &o_,
-                                        const EmitOut &out, const Advance &adv, uint32_t *chain, uint32_t flat_limit, uint32_t *sh) {
+                                        const EmitOut &out, const Advance &adv, uint32_t *chain, uint32_t flat_limit, uint32_t poll_limit, uint32_t *sh) {
     const uint32_t *st = in.st;
     const int axis = in.axis;
     const uint32_t t = tile * 256u + threadIdx.x;
@@ -359,7 +361,7 @@ __device__ __forceinline__ void kd_emit(uint32_t tile, uint32_t tiles, const Lev
     // no atomics (those on one address are served one after the other, a microsecond per hundred waves)
     const bool adds[4] = {splits, live && !splits && n != 0u, live && c == 0u, live && !splits && n == 0u};
     uint32_t rank[4], upto[4];
-    chained_ranks<4>(chain, tile, tiles, flat_limit, adds, sh, &out.counters[C_STALL], rank, upto);
+    chained_ranks<4>(chain, tile, tiles, flat_limit, adds, sh, &out.counters[C_STALL], poll_limit, rank, upto);
     // the sizes of the next level (the sums of this one are complete in the last workgroup)
     if (tile == tiles - 1u && threadIdx.x == 0u)
         kd_advance(adv, upto[0], upto[1], upto[2] + upto[3], upto[3], st, o_.st_next, out.counters);
@@ -422,10 +424,10 @@ __device__ __forceinline__ void kd_emit(uint32_t tile, uint32_t tiles, const Lev
 // The second launch of a level. Moving the faces and making the nodes read the sums over the level's flags and nothing
 // of each other: the first workgroups move, the others make nodes.
 __global__ __launch_bounds__(256) void k_kd_next(uint32_t scatter_blocks, LevelIn in, Nodes cur, Nodes nxt, LevelOut o_, EmitOut out,
-                                                 Advance adv, uint32_t *chain, uint32_t flat_limit) {
+                                                 Advance adv, uint32_t *chain, uint32_t flat_limit, uint32_t poll_limit) {
     __shared__ uint32_t sh[4 * CHAIN_SHARED_WORDS_PER_FLAG];
     if (blockIdx.x < scatter_blocks) kd_scatter(blockIdx.x, in, cur, o_, out);
-    else kd_emit(blockIdx.x - scatter_blocks, gridDim.x - scatter_blocks, in, cur, nxt, o_, out, adv, chain, flat_limit, sh);
+    else kd_emit(blockIdx.x - scatter_blocks, gridDim.x - scatter_blocks, in, cur, nxt, o_, out, adv, chain, flat_limit, poll_limit, sh);
 }
 
 __device__ __forceinline__ uint32_t code_of_heap(uint32_t heap) {
@@ -696,6 +698,10 @@ int GpuKdBuilder::build(hipStream_t s, const double *verts, int64_t n_verts, con
     // (for tests: the size from which the sums inside the kernels go in two steps, so that a small mesh can take that way)
     if (const char *e = getenv("RT_KD_CHAIN_FLAT")) chain_flat = (uint32_t)strtoul(e, nullptr, 10);
     else chain_flat = CHAIN_FLAT;
+    // how long a workgroup waits for the count of one in front of it before the build gives up (see chained_ranks)
+    if (const char *e = getenv("RT_KD_CHAIN_POLL_LIMIT")) poll_limit = (uint32_t)strtoul(e, nullptr, 10);
+    else poll_limit = CHAIN_POLL_LIMIT;
+    stalled = false;
     if (hist_levels > 0 && hist_faces == n_faces && hist_max_depth == max_depth && !getenv("RT_KD_BUILD_SYNC")) {
         const int r = build_once(s, verts, n_verts, faces, face_mat, n_faces, max_depth, infinity, true, err);
         if (r <= 0) return r;
@@ -768,7 +774,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
         chain_used += chain_words(gp, 2) + chain_words(2 * (uint64_t)ga, 4);
         if (!predicted) KCK(hipMemsetAsync(chain_test, 0, (size_t)(chain + chain_used - chain_test) * sizeof(uint32_t), s));
         hipLaunchKernelGGL(k_kd_test, blocks_for(gp), dim3(256), 0, s, d_verts, d_faces, pool_face[side], pool_owner[side],
-                           omap, st, gp, cur, axis, flags, scanned, chain_test, chain_flat, counters + C_STALL);
+                           omap, st, gp, cur, axis, flags, scanned, chain_test, chain_flat, counters + C_STALL, poll_limit);
         const unsigned sb = blocks_for(gp).x;
         // the children of the root and of every third level below it open new 16-slot blocks
         const bool opens_block = (d % 3 == 0);
@@ -779,7 +785,7 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
                            out,
                            Advance{scanned + gp, gp, ga, cap_pool, cap_level_nodes,
                                    predicted ? cap_node_slots : 0xffffffffu, ((d + 1) % 3 == 0) ? 1 : 0},
-                           chain_emit, chain_flat);
+                           chain_emit, chain_flat, poll_limit);
         KCK(hipGetLastError());
         levels = d + 1;
         if (!predicted) {
@@ -831,7 +837,11 @@ int GpuKdBuilder::build_once(hipStream_t s, const double *verts, int64_t n_verts
     KCK(hipEventRecord(ev1, s));
     KCK(hipStreamSynchronize(s));
     const uint32_t n_leaves = h_counters[C_LEAVES];
-    if (h_counters[C_STALL]) { err = "device k-d build: a workgroup waited for the flag count of another that never reported"; return -1; }
+    if (h_counters[C_STALL]) {
+        stalled = true;
+        err = "device k-d build: a workgroup waited for the flag count of another that never reported";
+        return -1;
+    }
     if (predicted) {
         // did every bound hold? A level larger than its grid was only partly processed: everything after it is void
         const uint32_t *last = h_lstate + (size_t)levels * ST_WORDS;

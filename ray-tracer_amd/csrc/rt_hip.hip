@@ -129,6 +129,7 @@ struct rt_ctx {
     KdTreeHost kd;
     GpuKdBuilder *gpu_kd = nullptr;              // device-side builder and its tree (rt_build_kdtree_device)
     bool kd_on_device = false;                   // the current tree is gpu_kd->tree, not `kd`
+    uint64_t kd_device_fallbacks = 0;            // device builds that stalled and were redone on the host
     bool kd_built = false, scene_dirty = true, mesh_dirty = true;
     SceneDev sh{};   // host mirror of the device scene header, as the frame in flight (and a repeat of it) uses it
     struct { float ambient[4], bg[4], cam[4], r00[4], r01[4], r10[4], r11[4]; } next{};   // rt_set_globals / rt_set_camera: taken over by the next rt_trace_begin
@@ -945,7 +946,17 @@ int rt_build_kdtree_device(rt_ctx *ctx) {
     // a tree of one node (at most four faces, or no depth to split in) is not worth a launch
     if (ctx->faces.size() / 3 <= 4 || ctx->cfg.max_kd_depth <= 1) return rt_build_kdtree(ctx);
     HIPCK(hipSetDevice(ctx->cfg.device));
-    if (device_build(ctx)) return -1;
+    if (device_build(ctx)) {
+        // A stalled build (a workgroup's wait for another's count ran out: the scheme leans on the order in which the
+        // hardware starts workgroups, which HIP does not promise) is no reason to fail a frame of an animation: the
+        // host builder makes the same tree. Anything else is an error. RT_KD_NO_FALLBACK keeps the failure (tests).
+        if (!(ctx->gpu_kd && ctx->gpu_kd->stalled) || getenv("RT_KD_NO_FALLBACK")) return -1;
+        fprintf(stderr, "rt_build_kdtree_device: %s; building this tree on the host instead\n", ctx->err.c_str());
+        ctx->kd_device_fallbacks++;
+        ctx->kd_on_device = false;
+        ctx->mesh_dirty = true;
+        return rt_build_kdtree(ctx);
+    }
     ctx->kd_on_device = true;
     ctx->kd_built = true;
     ctx->mesh_dirty = false;
@@ -1588,6 +1599,7 @@ int rt_device_shard_canvas(rt_ctx *ctx, void **dptr, size_t *bytes) {
 int rt_get_stats(rt_ctx *ctx, rt_stats *out) {
     if (!ctx) return -1;
     if (!out) return fail(ctx, "rt_get_stats: null argument");
+    ctx->st.kd_device_fallbacks = ctx->kd_device_fallbacks;
     *out = ctx->st;
     return 0;
 }

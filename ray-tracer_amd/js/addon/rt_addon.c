@@ -350,7 +350,7 @@ static napi_value js_stats(napi_env env, napi_callback_info info) {
 #define PUT(name, val) NAPI_OK(napi_create_double(env, (double)(val), &v)); NAPI_OK(napi_set_named_property(env, o, name, v));
     PUT("raysTotal", st.rays_total) PUT("shadowRays", st.shadow_rays) PUT("pixels", st.pixels) PUT("traceMs", st.trace_ms)
     PUT("compositeMs", st.composite_ms) PUT("toneMs", st.tone_ms) PUT("kdBuildMs", st.kd_build_ms) PUT("kdUploadMs", st.kd_upload_ms)
-    PUT("kdClosestRays", st.kd_closest_rays) PUT("kdShadowRays", st.kd_shadow_rays)
+    PUT("kdClosestRays", st.kd_closest_rays) PUT("kdShadowRays", st.kd_shadow_rays) PUT("kdDeviceFallbacks", st.kd_device_fallbacks)
 #undef PUT
     napi_value arr;
     NAPI_OK(napi_create_array_with_length(env, 8, &arr));

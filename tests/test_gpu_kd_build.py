@@ -330,3 +330,38 @@ def test_update_vertices_refuses_another_vertex_count():
     with pytest.raises(abi.RTError, match="another number of vertices"):
         rt.updateVertices(np.zeros((5, 3)))
     rt.close()
+
+
+def test_a_stalled_device_build_falls_back_to_the_host_builder(monkeypatch, capfd):
+    """The in-kernel sums of the device builder wait for workgroups with a lower index; the wait is bounded
+    (RT_KD_CHAIN_POLL_LIMIT polls). With a limit of 0 the first count that is not there yet ends the build as
+    stalled: rt_build_kdtree_device must say so, build the same tree on the host, and count the event - or, with
+    RT_KD_NO_FALLBACK, report the stall as the error it is. Without the limit the same context builds on the device again."""
+    m = manifest("k8_res2_640x480")
+    flat = make_flat("bun_zipper_res2.ply", 320, 240, depth=2)
+    ref = abi.RayTracerHIP(flat.cfg)
+    ref.setScene(flat)
+    ref.trace()
+    want = ref.readRGBA8()
+    rt = abi.RayTracerHIP(flat.cfg)
+    monkeypatch.setenv("RT_KD_CHAIN_POLL_LIMIT", "0")
+    rt.setScene(flat, kd_on_device=True)
+    assert "building this tree on the host instead" in capfd.readouterr().err
+    assert rt.stats().kd_device_fallbacks == 1
+    pairs, leaves, box = rt.exportKdTree()
+    assert sha(pairs) == m["kd"]["sha256"]["nodes_sparse_u32"] and sha(leaves) == m["kd"]["sha256"]["leaves_i32"]
+    rt.trace()
+    assert np.array_equal(rt.readRGBA8(), want)
+    monkeypatch.setenv("RT_KD_NO_FALLBACK", "1")
+    with pytest.raises(abi.RTError, match="never reported"):
+        rt.buildKdTree(on_device=True)
+    monkeypatch.delenv("RT_KD_NO_FALLBACK")
+    monkeypatch.delenv("RT_KD_CHAIN_POLL_LIMIT")
+    rt.buildKdTree(on_device=True)
+    assert rt.stats().kd_device_fallbacks == 1
+    pairs, leaves, box = rt.exportKdTree()
+    assert sha(pairs) == m["kd"]["sha256"]["nodes_sparse_u32"] and sha(leaves) == m["kd"]["sha256"]["leaves_i32"]
+    rt.trace()
+    assert np.array_equal(rt.readRGBA8(), want)
+    rt.close()
+    ref.close()
