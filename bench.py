@@ -39,7 +39,20 @@ FP32_PEAK_TFLOPS = 157.3
 VALU_ISSUE_PEAK = 2.0        # wave64 vector instructions per cycle per CU: four SIMD-32 units, two cycles each
 L2_PEAK_BS = 34.5e12         # aggregate L2 bandwidth
 L2_LINE_BYTES = 128.0
-PMC_DIGEST = "r02_pmc_digest.json"   # written by tools/prof.sh + tools/prof_summary.py for the committed kernels
+VALU_MIX_CEILING = 1.0       # what a CU issues of the walk's own instruction mix (compares, selects, IEEE division, three-operand
+                             # forms: 0.9 per cycle each; plain two-operand arithmetic 1.5 - 1.65): profiles/r02_valu_issue_rates.txt
+PMC_DIGEST = "r03_pmc_digest.json"   # written by tools/prof.sh + tools/prof_summary.py for the committed kernels
+
+
+def identity(args):
+    """What a PMC digest belongs to: the library binary and the workload. Counts per launch from a profile of another
+    binary or another workload say nothing about this run."""
+    import hashlib
+    with open(abi.LIB_PATH, "rb") as f:
+        lib = hashlib.sha256(f.read()).hexdigest()
+    return {"lib_sha256": lib, "workload": {"model": args.model, "teapot": int(args.teapot), "width": args.width, "height": args.height,
+                                            "depth": args.depth, "time": args.time, "shards": max(args.emulate_shards, 1),
+                                            "kd_builder": args.kd_builder, "gpus": args.gpus}}
 
 
 TEAPOT = (os.path.join(ROOT, "assets", "models", "teapot.obj"), 60.0, (50.0, 75.0, 10.0))   # file, scale, translation (checkpoint 6 places it so, js/6-transmission.js:2010-2014)
@@ -118,9 +131,14 @@ def main():
                     help="tiles: every frame is split over the GPUs (all-reduce + gather per frame); frames: step k is traced whole by rank k mod N, no exchange")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--device", type=int, default=None, help="HIP device for every rank (rehearsal on a one-GPU box); default LOCAL_RANK")
+    ap.add_argument("--opt", action="append", default=[], help="name=value: rt_set_option on every context (experiments)")
+    ap.add_argument("--identity", action="store_true", help="print the identity (library hash + workload) a PMC digest of this command line belongs to, and exit")
     ap.add_argument("--spawn-check", action="store_true", help="only start the ranks and add up their numbers over a gloo group (no GPU needed): checks the single-command launch")
     args = ap.parse_args()
 
+    if args.identity:
+        print(json.dumps(identity(args)))
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -172,6 +190,8 @@ def main():
         waves = args.walk_waves or (20 if (world > 1 and not by_frames) else 24)
         r.setOption("walk_waves_per_cu", waves)
         r.setOption("stage_timing", 0)     # per-kernel events only on the detail frames after the timed region
+        for kv in args.opt:
+            r.setOption(kv.split("=")[0], float(kv.split("=")[1]))
         rts.append(r)
     rt = rts[0]
     setup_s = (time.perf_counter() - t0) / n_ctx
@@ -357,9 +377,16 @@ def main():
         launches = np.array([D, n_steps, D, D], dtype=float)   # per frame: a level has a closest-hit half (steps 0..D-1) and a shadow half (steps 1..D)
         digest = {}
         dpath = os.path.join(ROOT, "profiles", PMC_DIGEST)
+        digest_note = "no committed PMC digest"
         if os.path.exists(dpath):
             with open(dpath) as f:
                 digest = json.load(f)
+            # per-launch instruction and request counts only mean something for the binary and workload they were taken on
+            if digest.get("__identity") == identity(args):
+                digest_note = "PMC digest matches this binary and workload"
+            else:
+                digest_note = "the committed PMC digest belongs to another binary or workload: counter-based figures left out"
+                digest = {}
         n_cus = torch.cuda.get_device_properties(local).multi_processor_count
         table = []
         for k in range(4):
@@ -384,7 +411,7 @@ def main():
         d = table[int(np.argmax(tot_ms))]
         out["roofline"] = {
             "bound": "valu_issue", "kernel": d["kernel"],
-            "achieved": d["valu_issue"], "peak": VALU_ISSUE_PEAK, "unit": "wave64 vector instructions per cycle per CU",
+            "achieved": d["valu_issue"], "peak": VALU_ISSUE_PEAK, "mix_ceiling": VALU_MIX_CEILING, "unit": "wave64 vector instructions per cycle per CU",
             "frac": None if d["valu_issue"] is None else d["valu_issue"] / VALU_ISSUE_PEAK,
             "traffic": d["traffic"],
             "l2_frac": d["l2_frac"], "hbm_frac": d["hbm_frac"],
@@ -393,12 +420,13 @@ def main():
             "reference_algorithm_tflops": d["reference_algorithm_tflops"],
             "avg_launch_ms": d["avg_launch_ms"], "launches_per_frame": d["launches_per_frame"],
             "valu_issue_frac_profiled": d["valu_issue_frac_profiled"], "lanes_per_valu_inst_profiled": d["lanes_per_valu_inst_profiled"],
-            "l2_hit_profiled": d["l2_hit_profiled"], "pmc_profile": "profiles/" + PMC_DIGEST,
+            "l2_hit_profiled": d["l2_hit_profiled"], "pmc_profile": "profiles/" + PMC_DIGEST, "pmc_profile_status": digest_note,
             "note": "frac = vector instructions issued per cycle and CU over the CU's peak of 2 (four SIMD-32, two cycles per wave64 instruction); "
+                    "mix_ceiling = what a CU can issue of this kernel's instruction mix (measured per opcode class, profiles/r02_valu_issue_rates.txt); "
                     "instruction and request counts per launch come from the committed rocprofv3 PMC passes of this binary on this workload, the "
                     "duration from HIP events in this run; l2_frac = TCC_REQ x 128 B / duration / 34.5 TB/s (an upper bound: a request may "
                     "carry 64 B); traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch = bytes that left L2 for the fabric, Infinity-Cache hits "
-                    "included, so hbm_frac is an upper bound (the leaf-ordered triangle table of 14 MB does not fit the 4 MB L2 of an XCD "
+                    "included, so hbm_frac is an upper bound (the leaf-ordered triangle table of 8.9 MB, the nodes and the tags do not fit the 4 MB L2 of an XCD "
                     "and is served by the Infinity Cache); neither HBM nor MFMA bounds this path",
         }
         out["kernels"] = table

@@ -1349,10 +1349,18 @@ int rt_luminance_sums_noalloc(const void *d_rgba8, uint64_t n_pixels, float L_ma
     if (!d_rgba8 || !d_sum_count) return bad("null buffer");
     if (n_pixels == 0) return bad("zero pixels");
     if (n_pixels > RT_NOALLOC_MAX_PIXELS) return bad("more than RT_NOALLOC_MAX_PIXELS (2^30) pixels");
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) return bad(std::string("hipSetDevice: ") + hipGetErrorString(e));
+    // the kernels go to `device`; the caller's current device is put back on every way out (a serving loop or a capture
+    // that finds another device current after this call would send its own launches to the wrong GPU)
+    int prev = -1;
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) return bad(std::string("hipGetDevice: ") + hipGetErrorString(e));
+    if (prev != device && (e = hipSetDevice(device)) != hipSuccess) return bad(std::string("hipSetDevice: ") + hipGetErrorString(e));
+    auto leave = [&](int rc) {
+        if (prev != device) (void)hipSetDevice(prev);
+        return rc;
+    };
     ToneScratch *sp = nullptr;
-    if ((e = scratch_on_current_device(device, &sp)) != hipSuccess) return bad(std::string("hipGetSymbolAddress: ") + hipGetErrorString(e));
+    if ((e = scratch_on_current_device(device, &sp)) != hipSuccess) return leave(bad(std::string("hipGetSymbolAddress: ") + hipGetErrorString(e)));
     // every word of the scratch that the second stage reads is written by the first stage of the same call, so
     // nothing needs clearing between calls
     const uint32_t n = (uint32_t)n_pixels;
@@ -1361,8 +1369,8 @@ int rt_luminance_sums_noalloc(const void *d_rgba8, uint64_t n_pixels, float L_ma
     hipLaunchKernelGGL(k_tone_partial, dim3(blocks), dim3(256), 0, s, (const uint32_t *)d_rgba8, n, (double)L_max, sp->part_sum, sp->part_cnt);
     hipLaunchKernelGGL(k_tone_final, dim3(1), dim3(64), 0, s, sp->part_sum, sp->part_cnt, blocks, &sp->out_sum, &sp->out_cnt,
                        (double *)d_sum_count);
-    if ((e = hipGetLastError()) != hipSuccess) return bad(std::string("launch: ") + hipGetErrorString(e));
-    return 0;
+    if ((e = hipGetLastError()) != hipSuccess) return leave(bad(std::string("launch: ") + hipGetErrorString(e)));
+    return leave(0);
 }
 
 int rt_pick(rt_ctx *ctx, int32_t x, int32_t y, int32_t *id) {

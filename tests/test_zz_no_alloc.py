@@ -28,6 +28,7 @@ def test_noalloc_luminance_sums_equal_rt_tone_partial():
         torch.cuda.synchronize()
         rc = L.rt_luminance_sums_noalloc(p, nb.value // 4, flat.cfg.L_max, C.c_void_p(out.data_ptr()), 0, None)
         assert rc == 0, L.rt_noalloc_last_error()
+        assert torch.cuda.current_device() == 0      # the caller's current device is as it was
         torch.cuda.synchronize()
         got = out.cpu().numpy()
         assert got[0] == want_sum and got[1] == float(want_cnt) == w * h, (got, want_sum, want_cnt)
@@ -43,3 +44,6 @@ def test_noalloc_luminance_sums_equal_rt_tone_partial():
     assert L.rt_luminance_sums_noalloc(p, (1 << 30) + 1, 1000.0, C.c_void_p(out.data_ptr()), 0, None) == -1
     assert b"RT_NOALLOC_MAX_PIXELS" in L.rt_noalloc_last_error()
     assert L.rt_luminance_sums_noalloc(None, 64, 1000.0, C.c_void_p(out.data_ptr()), 0, None) == -1
+    # a device that does not exist: refused, and the current device stays what it was
+    assert L.rt_luminance_sums_noalloc(p, 64, 1000.0, C.c_void_p(out.data_ptr()), 63, None) == -1
+    assert torch.cuda.current_device() == 0

@@ -16,5 +16,6 @@ for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST
   n=$(echo $pass | tr ' ' '_' | cut -c1-40)
   timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$n -o pmc -- python3 bench.py $ARGS > $OUT/pmc_$n.log 2>&1 || { echo "pmc pass failed: $pass"; tail -3 $OUT/pmc_$n.log; }
 done
+python3 bench.py $ARGS --identity > $OUT/identity.json 2>/dev/null
 python3 tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

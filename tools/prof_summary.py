@@ -110,5 +110,10 @@ for k in sorted(acc, key=lambda k: -acc[k].get("SQ_BUSY_CYCLES", 0)):
         d["hbm_bytes_per_launch"] = (2.0 * d["fetch_kib_per_launch"] + d["write_kib_per_launch"]) * 1024.0
         print("   -> HBM per launch: FETCH_SIZE %.1f KiB (x2 = %.1f KiB), WRITE_SIZE %.1f KiB, corrected total %.2f MB"
               % (d["fetch_kib_per_launch"], 2 * d["fetch_kib_per_launch"], d["write_kib_per_launch"], d["hbm_bytes_per_launch"] / 1e6))
+# which binary and workload the counts belong to (bench.py --identity, written by tools/prof.sh)
+ident = os.path.join(out, "identity.json")
+if os.path.exists(ident):
+    with open(ident) as fh:
+        digest["__identity"] = json.load(fh)
 with open(os.path.join(out, "digest.json"), "w") as fh:
     json.dump(digest, fh, indent=1, sort_keys=True)
