@@ -83,3 +83,23 @@ def device_canvas(rt):
     rt._ck(rt.L.rt_device_canvas(rt.ctx, C.byref(p), C.byref(n)), "rt_device_canvas")
     torch.cuda.synchronize()
     return torch.as_tensor(multi_gpu._DevView(p.value, n.value), device="cuda:%d" % rt.cfg.device).cpu().numpy().reshape(rt.cfg.height, rt.cfg.width, 4)
+
+
+def dragged_frames(model_name, frames, width, height, depth, mesh_material=None, **cfg_kw):
+    """benchmark configuration 5's motion: light 0 on the reference's orbit (UI.animate, js/8-kd_tree.js:2711-2716) and the mesh
+    dragged along a small circle with Mesh.translate (js/8-kd_tree.js:2055-2064: every vertex through the inverse of the old
+    float32 model matrix and through the new one), one translate per listed frame. Returns {frame: FlatScene}."""
+    import math
+    from ray_tracer_amd.three_f32 import Vector3
+    sc = scene.default_scene(model(model_name), mesh_material=mesh_material)
+    mesh = sc.objects[-1]
+    pos = lambda k: (12.0 * math.sin(2.0 * math.pi * k / 240.0), 0.0, 12.0 * (math.cos(2.0 * math.pi * k / 240.0) - 1.0))
+    out, prev = {}, 0
+    for k in frames:
+        p, q = pos(k), pos(prev)
+        if k != prev:
+            mesh.translate(Vector3(p[0] - q[0], p[1] - q[1], p[2] - q[2]))
+        prev = k
+        scene.animate_light(sc, k / 60.0)
+        out[k] = abi.FlatScene(sc, abi.default_config(width, height, depth=depth, **cfg_kw), scene.camera_rays(width, height))
+    return out

@@ -183,79 +183,92 @@ def test_frames_do_not_depend_on_where_the_tree_was_built():
 
 
 def test_animated_frames_with_rebuild_match_the_oracle():
-    """benchmark configuration 5 in small: light 0 on its orbit, the mesh dragged, the tree rebuilt on the device for every
-    frame, three frames in flight on alternating contexts. Every frame must equal the oracle's render of that
-    frame's scene (the oracle builds its own tree from the moved vertices)."""
-    import copy
-    import math
+    """benchmark configuration 5 in small: light 0 on its orbit, the mesh dragged with Mesh.translate (float32 matrix round trip
+    of every vertex, as the reference's drag does it), the tree rebuilt on the device for every frame, three frames in
+    flight on alternating contexts. Every frame must equal the oracle's render of that frame's scene (the oracle builds
+    its own tree from the moved vertices)."""
     import torch
+    from helpers import dragged_frames
     from ray_tracer_amd import multi_gpu
-    flat = make_flat("bun_zipper_res4.ply", 160, 120, depth=3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
-    base = np.ascontiguousarray(flat.verts, np.float64)
+    frames = [0, 30, 60, 90, 120, 150]
+    flats = dragged_frames("bun_zipper_res4.ply", frames, 160, 120, 3, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9))
+    flat = flats[0]
+    assert not np.array_equal(flats[30].verts, flats[0].verts)
     rts = []
     for _ in range(3):
         rt = abi.RayTracerHIP(flat.cfg)
         rt.setScene(flat, kd_on_device=True)
         rts.append(rt)
     job = multi_gpu.PipelinedFrameJob(rts, multi_gpu.Comm(0, 1, 0, backend=None, device="cuda:0"))
-
-    def scene_of(k):
-        t = k / 60.0
-        x = 500.0 * math.cos(2.0 * math.pi * (t % 60.0) / 60.0)
-        lights = [((x, 300.0, x - 280.0), flat.lights[0][1])] + list(flat.lights[1:])
-        a = 2.0 * math.pi * k / 240.0
-        return lights, base + np.array([12.0 * math.sin(a), 0.0, 12.0 * (math.cos(a) - 1.0)])
-
-    frames = [0, 30, 60, 90, 120, 150]
     for k in frames:
-        lights, verts = scene_of(k)
+        f = flats[k]
         rt = job.next_context()
-        rt.setLights(lights, flat.n_lights_loop)
-        rt.setMesh(verts, flat.faces, flat.face_mat)
+        rt.setLights(f.lights, f.n_lights_loop)
+        rt.setMesh(f.verts, f.faces, f.face_mat)
         rt.buildKdTree(on_device=True)
         job.step()
     job.flush()
     torch.cuda.synchronize()
     for slot, k in ((0, frames[3]), (1, frames[4]), (2, frames[5])):   # the last frame of each context
-        f = copy.copy(flat)
-        f.lights, f.verts = scene_of(k)
-        want_f, want_8, want_id, cn = oracle.OracleRenderer(f).trace(threads=16)
+        want_f, want_8, want_id, cn = oracle.OracleRenderer(flats[k]).trace(threads=16)
         rt = rts[slot]
         assert np.array_equal(rt.readHitIds(), want_id), k
         assert np.array_equal(rt.readRGBA8(), want_8), k
         assert np.array_equal(rt.readFloat(), want_f, equal_nan=True), k
         assert rt.stats().rays_total == cn.rays
+    job.close()
 
 
 def test_one_animated_frame_at_full_size_matches_the_oracle():
     """The animated benchmark at its real size: full bunny, 3840x2160, depth 4, frame 37 of the run (light 0 on its
-    orbit, the mesh moved along its circle), the tree rebuilt on the device - after a first build at rest, so that this
-    is a rebuild over predicted sizes. The whole frame must equal the oracle's render of the moved scene."""
-    import copy
-    import math
-    flat = make_flat("bun_zipper.ply", 3840, 2160, depth=4)
-    base = np.ascontiguousarray(flat.verts, np.float64)
+    orbit, the mesh moved along its circle with Mesh.translate), the tree rebuilt on the device - after a first build at
+    rest, so that this is a rebuild over predicted sizes. The whole frame must equal the oracle's render of the moved scene."""
+    from helpers import dragged_frames
+    flats = dragged_frames("bun_zipper.ply", [0, 37], 3840, 2160, 4)
+    flat, f = flats[0], flats[37]
     rt = abi.RayTracerHIP(flat.cfg)
     rt.setScene(flat, kd_on_device=True)
     rt.trace()
-    k = 37
-    t = k / 60.0
-    x = 500.0 * math.cos(2.0 * math.pi * (t % 60.0) / 60.0)
-    lights = [((x, 300.0, x - 280.0), flat.lights[0][1])] + list(flat.lights[1:])
-    a = 2.0 * math.pi * k / 240.0
-    verts = base + np.array([12.0 * math.sin(a), 0.0, 12.0 * (math.cos(a) - 1.0)])
-    rt.setLights(lights, flat.n_lights_loop)
-    rt.setMesh(verts, flat.faces, flat.face_mat)
+    rt.setLights(f.lights, f.n_lights_loop)
+    rt.setMesh(f.verts, f.faces, f.face_mat)
     rt.buildKdTree(on_device=True)
     rt.trace()
-    f = copy.copy(flat)
-    f.lights, f.verts = lights, verts
     want_f, want_8, want_id, cn = oracle.OracleRenderer(f).trace(threads=16)
     assert np.array_equal(rt.readHitIds(), want_id)
     assert np.array_equal(rt.readRGBA8(), want_8)
     assert np.array_equal(rt.readFloat(), want_f, equal_nan=True)
     st = rt.stats()
     assert st.rays_total == cn.rays and st.shadow_rays == cn.shadow_rays
+    rt.close()
+
+
+def test_config5_with_the_project_scenes_supersampling_2_lattice_parity():
+    """benchmark configuration 5 as project.js is configured: SUPERSAMPLING 2, i.e. a 7680x4320 render target behind a 3840x2160
+    canvas, depth 4, an animated frame (mesh moved with Mesh.translate, tree rebuilt on the device). The oracle traces a
+    lattice of every 12th pixel in x and y (230 400 pixels) and two 64x64 windows on the bunny; hit ids, bytes and float
+    colours must be equal there."""
+    from helpers import dragged_frames
+    flats = dragged_frames("bun_zipper.ply", [0, 23], 3840, 2160, 4, supersampling=2)
+    f = flats[23]
+    rt = abi.RayTracerHIP(f.cfg)
+    rt.setScene(f, kd_on_device=True)
+    rt.trace()
+    a8, af, aid = rt.readRGBA8(), rt.readFloat(), rt.readHitIds()
+    assert a8.shape == (4320, 7680, 4) and rt.stats().pixels == 7680 * 4320
+    o = oracle.OracleRenderer(f)
+    wf, w8, wid, _ = o.trace(step=12, threads=16)
+    lat = (slice(0, None, 12), slice(0, None, 12))
+    assert np.array_equal(aid[lat], wid[lat]) and np.array_equal(a8[lat], w8[lat])
+    assert ((af[lat] == wf[lat]) | (np.isnan(af[lat]) & np.isnan(wf[lat]))).all()
+    n_prims = len(f.prims)
+    ys, xs = np.nonzero(aid >= n_prims)
+    assert len(ys) > 100000                                   # the mesh fills a good part of the frame
+    cy, cx = int(np.median(ys)), int(np.median(xs))
+    for rect in ((cx - 32, cy - 32, cx + 32, cy + 32), (int(xs.min()), cy - 32, int(xs.min()) + 64, cy + 32)):
+        wf, w8, wid, _ = o.trace(rect=rect, threads=16)
+        sl = (slice(rect[1], rect[3]), slice(rect[0], rect[2]))
+        assert np.array_equal(aid[sl], wid[sl]) and np.array_equal(a8[sl], w8[sl]), rect
+        assert ((af[sl] == wf[sl]) | (np.isnan(af[sl]) & np.isnan(wf[sl]))).all(), rect
     rt.close()
 
 

@@ -585,6 +585,23 @@ def test_supersampled_4k_target_ward_and_reinhard_present():
     assert not np.array_equal(reinhard, ward)
 
 
+def test_reinhard_and_ward_present_onto_a_3840x2160_canvas():
+    """benchmark configuration 4 at its size: the 3840x2160 frame of the bunny scene (depth 2) presented with both tone operators;
+    Lbar / sf against the reference's sequential loop, and the whole canvas equal to the oracle's present pass."""
+    for method in (1, 0):
+        flat = make_flat("bun_zipper_res2.ply", 3840, 2160, depth=2, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.5, 0.9), tr_method=method)
+        rt = render_hip(flat)
+        g8 = rt.readRGBA8()
+        o = oracle.OracleRenderer(flat)
+        Lbar, sf = rt.tone()
+        wl, ws = o.tone(g8)
+        assert abs(Lbar - wl) <= 1e-8 * wl and np.float32(sf) == np.float32(ws) and np.float32(Lbar) == np.float32(wl)
+        canvas = rt.present()
+        assert canvas.shape == (2160, 3840, 4)
+        assert np.array_equal(canvas, o.present(g8, wl, ws)), method
+        rt.close()
+
+
 def test_buffers_too_small_for_the_first_frame_are_grown_and_the_frame_repeated():
     """rt_trace sizes the ray-tree levels and the leaf-record buffers from earlier frames; a frame that does not fit
     is traced again with larger buffers (rt_trace_end returns 1). Started far too small, the result must still be
