@@ -99,6 +99,7 @@ def main():
     rays = sync.sum_int(job.rays)
     shadow = sync.sum_int(job.shadow_rays)
     build_ms = rts[0].stats().kd_build_ms
+    upload_ms = rts[0].stats().kd_upload_ms
     if rank == 0:
         print(json.dumps({
             "metric": "frames/s, animated project scene with a k-d rebuild per frame", "value": args.frames / dt, "unit": "frames/s",
@@ -108,7 +109,7 @@ def main():
                                    % (args.model, args.width, args.height, args.ss, args.depth,
                                       "no rebuild" if args.static else "tree rebuilt every frame by the %s builder" % args.kd_builder),
                        "frames_in_flight": len(rts), "sharding": "frame k on rank k mod N, no exchange"},
-            "kd_build_ms_last": build_ms, "frames_retraced": job.redone}))
+            "kd_build_ms_last": build_ms, "kd_upload_ms_last": upload_ms, "frames_retraced": job.redone}))
     sync.close()
 
 

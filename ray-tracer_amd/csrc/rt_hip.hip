@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <array>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_hip.h"
@@ -40,6 +42,7 @@ struct SharedTree {
     uint32_t *path_slot = nullptr;
     float *leaf_box = nullptr;                   // float32 cell of every leaf with faces, indexed by TriTag::leaf
     int refs = 0;
+    bool findable = true;                        // hash / sum describe the contents: other contexts may take this copy for theirs
 };
 std::mutex g_shared_mu;
 std::vector<SharedTree *> g_shared;
@@ -347,13 +350,16 @@ void refresh_tris_host(rt_ctx *ctx) {
 }
 
 void tree_overhang(rt_ctx *ctx, const KdTreeHost &kd, std::vector<float> *leaf_boxes = nullptr) {
-    if (leaf_boxes) leaf_boxes->assign(6 * kd.leaves.size(), 0.0f);
-    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    // cells first (one pass over the nodes), then the listed faces against them, leaves spread over a few threads
+    std::vector<float> own;
+    std::vector<float> &boxes = leaf_boxes ? *leaf_boxes : own;
+    boxes.assign(6 * kd.leaves.size(), 0.0f);
     struct Item { uint32_t node; float bmin[3], bmax[3]; };
     std::vector<Item> todo;
-    Item root{0u, {(float)kd.root_box[0], (float)kd.root_box[1], (float)kd.root_box[2]},
-              {(float)kd.root_box[3], (float)kd.root_box[4], (float)kd.root_box[5]}};
-    if (!kd.nodes.empty()) todo.push_back(root);
+    todo.reserve(64);
+    if (!kd.nodes.empty())
+        todo.push_back(Item{0u, {(float)kd.root_box[0], (float)kd.root_box[1], (float)kd.root_box[2]},
+                            {(float)kd.root_box[3], (float)kd.root_box[4], (float)kd.root_box[5]}});
     while (!todo.empty()) {
         const Item it = todo.back();
         todo.pop_back();
@@ -367,26 +373,40 @@ void tree_overhang(rt_ctx *ctx, const KdTreeHost &kd, std::vector<float> *leaf_b
             todo.push_back(c0);
             todo.push_back(c1);
         } else if (ty == 3u) {
-            const KdLeafDev &lf = kd.leaves[n.info & 0x3fffffffu];
-            if (leaf_boxes)
-                for (int c = 0; c < 3; c++) {
-                    (*leaf_boxes)[6 * (size_t)(n.info & 0x3fffffffu) + c] = it.bmin[c];
-                    (*leaf_boxes)[6 * (size_t)(n.info & 0x3fffffffu) + 3 + c] = it.bmax[c];
-                }
+            float *b = &boxes[6 * (size_t)(n.info & 0x3fffffffu)];
+            for (int c = 0; c < 3; c++) { b[c] = it.bmin[c]; b[3 + c] = it.bmax[c]; }
+        }
+    }
+    std::vector<float> v32(ctx->verts.size());
+    for (size_t i = 0; i < v32.size(); i++) v32[i] = (float)ctx->verts[i];
+    const size_t n_leaves = kd.leaves.size();
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>({8, (size_t)std::max(1u, std::thread::hardware_concurrency()), n_leaves / 4096 + 1}));
+    std::vector<std::array<float, 6>> part((size_t)nt, std::array<float, 6>{0, 0, 0, 0, 0, 0});
+    auto work = [&](int t) {
+        std::array<float, 6> m{0, 0, 0, 0, 0, 0};
+        for (size_t li = n_leaves * (size_t)t / nt; li < n_leaves * (size_t)(t + 1) / nt; li++) {
+            const float *b = &boxes[6 * li];
             for (int k = 0; k < 4; k++) {
-                if (lf.face[k] < 0) continue;
+                const int32_t f = kd.leaves[li].face[k];
+                if (f < 0) continue;
                 for (int j = 0; j < 3; j++) {
-                    const double *v = &ctx->verts[3 * (size_t)ctx->faces[3 * (size_t)lf.face[k] + j]];
+                    const float *v = &v32[3 * (size_t)ctx->faces[3 * (size_t)f + j]];
                     for (int c = 0; c < 3; c++) {
-                        const float x = (float)v[c];
-                        lo[c] = std::max(lo[c], it.bmin[c] - x);
-                        hi[c] = std::max(hi[c], x - it.bmax[c]);
+                        m[c] = std::max(m[c], b[c] - v[c]);
+                        m[3 + c] = std::max(m[3 + c], v[c] - b[3 + c]);
                     }
                 }
             }
         }
-    }
-    const float raw[6] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
+        part[(size_t)t] = m;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    float raw[6] = {0, 0, 0, 0, 0, 0};
+    for (const auto &m : part)
+        for (int c = 0; c < 6; c++) raw[c] = std::max(raw[c], m[c]);
     kd_overhang_with_margin(raw, kd.root_box, ctx->over);
     ctx->over_valid = true;
 }
@@ -510,24 +530,30 @@ int upload_scene(rt_ctx *ctx) {
         }
         std::vector<float> leaf_box;
         tree_overhang(ctx, kd, &leaf_box);
-        Digest dg;
-        tree_digest(nodes.data(), nodes.size() * sizeof(KdNodeDev), dg);
-        tree_digest(lgeo.data(), lgeo.size() * sizeof(TriGeo), dg);
-        tree_digest(ltag.data(), ltag.size() * sizeof(TriTag), dg);
         const size_t n_leaves = kd.leaves.size();
         SharedTree *mine = nullptr;   // the copy this context may overwrite: it is its only holder and the new tree fits
         {
             std::lock_guard<std::mutex> lock(g_shared_mu);
             SharedTree *old = ctx->shared;
             if (old && old->refs == 1 && old->device == ctx->cfg.device && old->cap_nodes >= nodes.size() &&
-                old->cap_slots >= lgeo.size() && old->cap_leaves >= n_leaves)
+                old->cap_slots >= lgeo.size() && old->cap_leaves >= n_leaves) {
                 mine = old;
+                mine->findable = false;   // its contents change now; a tree that is rebuilt over and over is not offered for sharing
+            }
+        }
+        // The digests cost a pass over some fifteen megabytes; a context that rebuilds its own tree (moving geometry)
+        // neither looks for a copy to share nor offers its own
+        Digest dg;
+        if (!mine) {
+            tree_digest(nodes.data(), nodes.size() * sizeof(KdNodeDev), dg);
+            tree_digest(lgeo.data(), lgeo.size() * sizeof(TriGeo), dg);
+            tree_digest(ltag.data(), ltag.size() * sizeof(TriTag), dg);
         }
         if (!mine) detach_shared_tree(ctx);
         if (!mine) {   // another context of this process may hold this very tree on this GPU already
             std::lock_guard<std::mutex> lock(g_shared_mu);
             for (SharedTree *t : g_shared)
-                if (t->device == ctx->cfg.device && t->hash == dg.h && t->sum == dg.s && t->n_nodes == nodes.size() &&
+                if (t->findable && t->device == ctx->cfg.device && t->hash == dg.h && t->sum == dg.s && t->n_nodes == nodes.size() &&
                     t->n_slots == lgeo.size() && t->n_leaves == n_leaves) {
                     t->refs++;
                     ctx->shared = t;
