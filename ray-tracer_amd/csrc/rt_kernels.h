@@ -337,6 +337,10 @@ static_assert(63 + WALK_ACTIONS * 64 <= TEST_RING, "the ring must hold what the 
 #define RT_TEST_MIN_DRY 64
 #endif
 constexpr uint32_t TEST_MIN_DRY = RT_TEST_MIN_DRY;   // records that trigger a test round once the global queue is dry
+#ifndef RT_TEST_MIN_CLOSEST
+#define RT_TEST_MIN_CLOSEST 64
+#endif
+constexpr uint32_t TEST_MIN_CLOSEST = RT_TEST_MIN_CLOSEST;   // the same while the queue still has rays, closest-hit job (a hit found earlier prunes earlier)
 
 // wave-uniform values are passed through readfirstlane so that they live in scalar registers and
 // conditions on them compile to scalar branches instead of lane-mask arithmetic
@@ -467,7 +471,7 @@ __device__ __forceinline__ void walk_job(const SceneDev &S, const WalkJob &J, ui
         for (;;) {
             const uint32_t waiting = UNIFORM(ring_tail - ring_head);
             if (waiting == 0u) break;
-            if (waiting < (UNIFORM(more) ? (uint32_t)WAVE : TEST_MIN_DRY) && __builtin_amdgcn_ballot_w64(info != 0u) != 0ull) break;
+            if (waiting < (UNIFORM(more) ? (ANY ? (uint32_t)WAVE : TEST_MIN_CLOSEST) : TEST_MIN_DRY) && __builtin_amdgcn_ballot_w64(info != 0u) != 0ull) break;
             const uint32_t n = min(waiting, (uint32_t)WAVE);
             const bool mine = test_round<ANY>(S, J, ring, hit_flag, ring_head, n, lane, ox, oy, oz, dx, dy, dz, ref);
             ring_head = UNIFORM(ring_head + n);
