@@ -61,6 +61,7 @@ function parseArgs(argv) {
         else if (k === '--drag') a.drag = argv[++i].split(',').map(Number);
         else if (k === '--trackball') a.trackball = argv[++i].split(',');
         else if (k === '--set') { const [n, v] = argv[++i].split('='); a.sets[n] = v; }
+        else if (k === '--dump-glsl') a.dumpGlsl = argv[++i];   // directory OUTSIDE the repository: shader sources + texture payloads for oracle/gen_golden/glsl_exec
         else throw new Error('unknown arg ' + k);
     }
     if (!a.out) throw new Error('--out required');
@@ -286,6 +287,34 @@ setImmediate(() => {
         trackballRecord.last_time = t;
     }
 
+    if (args.dumpGlsl) {
+        // The generated shader text and the data it reads, for the build-container-only execution harness
+        // (oracle/gen_golden/glsl_exec). The text is the reference's: it must not land inside the repository.
+        const repo = path.resolve(__dirname, '..', '..');
+        const dir = path.resolve(args.dumpGlsl);
+        if (dir === repo || dir.startsWith(repo + path.sep)) throw new Error('--dump-glsl must point outside the repository');
+        fs.mkdirSync(dir, { recursive: true });
+        shaderSources.forEach((src, i) => fs.writeFileSync(path.join(dir, 'shader' + i + '.glsl'), src));
+        const tex = [];
+        let unit = null, nTex = 0;
+        for (const [fn, a] of glCalls) {
+            if (fn === 'activeTexture') unit = a[0];
+            if ((fn === 'texSubImage2D' || fn === 'texImage2D') && a[a.length - 1] && a[a.length - 1].buffer) {
+                const ta = a[a.length - 1];
+                const name = 'tex' + (nTex++) + '.bin';
+                fs.writeFileSync(path.join(dir, name), Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength));
+                tex.push({ file: name, call: fn, unit, args: a.slice(0, a.length - 1).map((v) => (typeof v === 'object' ? null : v)), type: ta.constructor.name, length: ta.length });
+            }
+        }
+        const un = [];
+        for (const [fn, a] of glCalls) {
+            if (/^uniform(Matrix)?[1-4][fi]v?$/.test(fn)) {
+                const val = fn.startsWith('uniformMatrix') ? a[2] : a[1];
+                un.push({ name: a[0], fn, value: (typeof val === 'number') ? [val] : Array.from(val) });
+            }
+        }
+        fs.writeFileSync(path.join(dir, 'dump.json'), JSON.stringify({ script: args.script, width: args.width, height: args.height, traced_width: get('Number(WIDTH) * (typeof SUPERSAMPLING !== "undefined" ? SUPERSAMPLING : 1)'), traced_height: get('Number(HEIGHT) * (typeof SUPERSAMPLING !== "undefined" ? SUPERSAMPLING : 1)'), textures: tex, uniforms: un }));
+    }
     fs.mkdirSync(args.out, { recursive: true });
     const sha = (buf) => crypto.createHash('sha256').update(Buffer.from(buf.buffer, buf.byteOffset, buf.byteLength)).digest('hex');
     const writeBin = (name, ta) => fs.writeFileSync(path.join(args.out, name), Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength));
