@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Build container only: random scenes through the reference's OWN code path and through the oracle.
+
+For every seed a scene is drawn (every primitive kind under random scale / rotation / translation, the three material
+types with random constants, one to three lights, the camera moved off its default place, the small bunny under a random
+transform, recursion depth 2 .. 5) and realised twice from one description:
+  * as JavaScript against the reference's classes (`new Cube(nextObjectId++)`, `.scale(new THREE.Vector3(...))`, ...):
+    ref_capture.js appends it to the reference's page script as another generateScene(), so the REFERENCE computes the
+    matrices, the uniforms, the k-d tree and textures and generates the shader text for that scene; glsl2cpp.py then executes
+    that text for every pixel;
+  * as Python against ray-tracer_amd/scene.py (the twin the tests use), rendered by the CPU oracle with the camera
+    uniforms the reference produced.
+The two float32 frames must be equal bit for bit. Usage:
+    python oracle/gen_golden/glsl_exec/random_scenes.py FIRST_SEED END_SEED [--keep N]
+--keep N stores the first N scenes as fixtures under tests/golden/glsl_exec/ (description + pixels; never the shader text),
+which tests/test_glsl_exec_golden.py picks up. Everything else happens under /tmp.
+"""
+import json
+import math
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", "..", ".."))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import rt_loader  # noqa: E402
+
+rt_loader.load()
+SCRATCH = "/tmp/glsl_exec_random"
+W, H = 96, 64
+MODEL = "bun_zipper_res4.ply"
+
+
+def describe(seed):
+    """The scene as plain data (JSON-serialisable; every number a Python float that both realisations read alike)."""
+    rng = np.random.default_rng(seed)
+    u = lambda a, b: float(rng.uniform(a, b))
+    d = {"seed": seed, "depth": 2 + seed % 4, "time": round(u(0.0, 59.0), 3),
+         "lights": [{"pos": [u(-400, 400), u(50, 400), u(-500, 200)], "color": [u(0.2, 1), u(0.2, 1), u(0.2, 1)]}
+                    for _ in range(int(rng.integers(1, 4)))],
+         "ambient": [u(0.2, 0.9), u(0.2, 0.9), u(0.2, 0.9)], "bg": [u(0, 1), u(0, 1), u(0, 1)],
+         "materials": [], "objects": []}
+
+    def material():
+        kind = ["Phong", "PhongBlinn", "PhongCheckered"][int(rng.integers(0, 3))]
+        kr = u(0.2, 0.8) if rng.random() < 0.7 else 0.0
+        kt = u(0.3, 0.9) if rng.random() < 0.5 else 0.0
+        m = {"type": kind, "k": [u(0.05, 0.6), u(0.1, 0.9), u(0.1, 1.0), float(rng.integers(4, 40)), kr, kt, u(0.7, 1.6)],
+             "colors": [[u(0, 1), u(0, 1), u(0, 1)] for _ in range(3 if kind == "PhongCheckered" else 2)]}
+        d["materials"].append(m)
+        return len(d["materials"]) - 1
+
+    kinds = ["Sphere", "Cube", "Cylinder", "Rectangle", "Sphere", "Cube", "Cylinder"]
+    rng.shuffle(kinds)
+    for kind in kinds[:int(rng.integers(3, 8))]:
+        if kind == "Rectangle":
+            o = {"kind": kind, "scale": [u(100, 600), 1.0, u(100, 900)], "rotate": [u(-0.3, 0.3), u(-1, 1), u(-0.3, 0.3)],
+                 "translate": [u(-100, 100), u(-120, -40), u(-400, -200)]}
+        else:
+            o = {"kind": kind, "scale": [u(15, 70), u(15, 70), u(15, 70)],
+                 "rotate": [u(-math.pi, math.pi), u(-math.pi, math.pi), u(-math.pi, math.pi)],
+                 "translate": [u(-150, 150), u(-60, 120), u(-450, -150)]}
+        o["material"] = material()
+        d["objects"].append(o)
+    if rng.random() < 0.5:
+        d["objects"].append({"kind": "Plane", "scale": None, "rotate": None, "translate": [0.0, u(-300, -150), 0.0], "material": material()})
+    s = u(500, 1200)
+    d["mesh"] = {"scale": [s, s, s], "rotate": [u(-1, 1), u(-math.pi, math.pi), u(-1, 1)], "translate": [u(-60, 60), u(-40, 60), u(-320, -200)],
+                 "material": material()}
+    d["camera_pos"] = [u(-80, 80), u(-20, 100), u(-20, 120)]
+    return d
+
+
+def js_scene(d):
+    """generateScene() for the reference's page script (its classes, its id counters, its globals)."""
+    num = lambda v: repr(float(v))
+    vec = lambda v: "new THREE.Vector3(%s)" % ", ".join(num(x) for x in v)
+    L = ["function generateScene(meshes) {", "    var objects = [], materials = [], lights = [];"]
+    for l in d["lights"]:
+        L.append("    lights.push(new PointLight(nextPointLightId++, %s, %s));" % (vec(l["pos"]), vec(l["color"])))
+    counter = {"Phong": "nextPhongId", "PhongBlinn": "nextPhongBlinnId", "PhongCheckered": "nextPhongCheckeredId"}
+    for i, m in enumerate(d["materials"]):
+        L.append("    var m%d = new %s(%s++, %s, %s);" % (i, m["type"], counter[m["type"]], ", ".join(num(x) for x in m["k"]),
+                                                       ", ".join(vec(c) for c in m["colors"])))
+        L.append("    materials.push(m%d);" % i)
+    L += ["    g_verts = [];", "    g_faces = [];"]
+
+    def place(name, o):
+        if o["scale"] is not None:
+            L.append("    %s.scale(%s);" % (name, vec(o["scale"])))
+        if o["rotate"] is not None:
+            L.append("    %s.rotate(new THREE.Euler(%s, 'XYZ'));" % (name, ", ".join(num(x) for x in o["rotate"])))
+        L.append("    %s.translate(%s);" % (name, vec(o["translate"])))
+        L.append("    %s.setMaterial(m%d);" % (name, o["material"]))
+        L.append("    objects.push(%s);" % name)
+    for i, o in enumerate(d["objects"]):
+        L.append("    var o%d = new %s(nextObjectId++);" % (i, o["kind"]))
+        place("o%d" % i, o)
+    L.append("    var mesh = new Mesh(nextObjectId++, meshes[MODEL_FILE_NAME].verts, meshes[MODEL_FILE_NAME].faces);")
+    place("mesh", d["mesh"])
+    # the camera: only its place; the reference's controls aim it (TrackballControls.update looks at its target)
+    L.append("    camera.position.set(%s);" % ", ".join(num(x) for x in d["camera_pos"]))
+    L.append("    return { objects: objects, materials: materials, lights: lights, ambientLight: %s, bgColor: %s };" % (vec(d["ambient"]), vec(d["bg"])))
+    L.append("}")
+    return "\n".join(L) + "\n"
+
+
+def py_scene(d):
+    """The same description on the Python twin of the scene classes."""
+    from ray_tracer_amd import scene
+    from ray_tracer_amd.three_f32 import Euler, Vector3 as V
+    from helpers import model
+    sc = scene.Scene()
+    ids = sc.ids
+
+    def nid(name):
+        v = getattr(ids, name)
+        setattr(ids, name, v + 1)
+        return v
+    for l in d["lights"]:
+        sc.lights.append(scene.PointLight(nid("light"), V(*l["pos"]), V(*l["color"])))
+    sc.n_lights_declared = ids.light
+    mats = []
+    for m in d["materials"]:
+        cls, counter = {"Phong": (scene.Phong, "phong"), "PhongBlinn": (scene.PhongBlinn, "blinn"),
+                        "PhongCheckered": (scene.PhongCheckered, "checkered")}[m["type"]]
+        mats.append(cls(nid(counter), *m["k"], *[V(*c) for c in m["colors"]]))
+        sc.materials.append(mats[-1])
+
+    def place(o, spec):
+        if spec["scale"] is not None:
+            o.scale(V(*spec["scale"]))
+        if spec["rotate"] is not None:
+            o.rotate(Euler(*spec["rotate"], "XYZ"))
+        o.translate(V(*spec["translate"]))
+        o.setMaterial(mats[spec["material"]])
+        sc.objects.append(o)
+    for spec in d["objects"]:
+        place(getattr(scene, spec["kind"])(nid("object")), spec)
+    v, f = scene.load_ply(model(MODEL))
+    place(scene.Mesh(nid("object"), v, f, sc.meshes), d["mesh"])
+    sc.ambientLight = V(*d["ambient"])
+    sc.bgColor = V(*d["bg"])
+    scene.animate_light(sc, d["time"])
+    return sc
+
+
+def camera_of(dump):
+    """cameraPos and the corner rays as the reference handed them to WebGL (last value of each uniform)."""
+    with open(os.path.join(dump, "dump.json")) as f:
+        meta = json.load(f)
+    last = {}
+    for un in meta["uniforms"]:
+        last[un["name"]] = un["value"]
+    return {k: np.array(last[k], np.float32) for k in ("cameraPos", "ray00", "ray01", "ray10", "ray11")}
+
+
+def oracle_frame(d, cam):
+    from oracle import oracle
+    from ray_tracer_amd import abi
+    flat = abi.FlatScene(py_scene(d), abi.default_config(W, H, depth=d["depth"]), cam)
+    o = oracle.OracleRenderer(flat)
+    rgb, rgba, ids, cn = o.trace()
+    return rgb, ids, flat
+
+
+def run_seed(seed, keep_dir=None):
+    d = describe(seed)
+    dump = os.path.join(SCRATCH, "s%d" % seed)
+    shutil.rmtree(dump, ignore_errors=True)
+    os.makedirs(dump)
+    with open(os.path.join(dump, "scene.js"), "w") as f:
+        f.write(js_scene(d))
+    subprocess.check_call(["node", os.path.join(REPO, "oracle", "gen_golden", "ref_capture.js"), "--script", "8-kd_tree.js",
+                           "--model", "models/" + MODEL, "--width", str(W), "--height", str(H), "--depth", str(d["depth"]),
+                           "--time", repr(d["time"]), "--scene-js", os.path.join(dump, "scene.js"),
+                           "--out", os.path.join(dump, "manifest"), "--dump-glsl", dump], stdout=subprocess.DEVNULL)
+    out = os.path.join(dump, "tracer.f32")
+    subprocess.check_call([sys.executable, os.path.join(HERE, "glsl2cpp.py"), dump, out, "--step", "1"], stdout=subprocess.DEVNULL)
+    want = np.fromfile(out, np.float32).reshape(H, W, 3)
+    cam = camera_of(dump)
+    got, ids, flat = oracle_frame(d, cam)
+    diff = (got.view(np.uint32) != want.view(np.uint32)).any(-1)
+    kinds = len(np.unique(ids))
+    if keep_dir and not diff.any():
+        os.makedirs(keep_dir, exist_ok=True)
+        want.tofile(os.path.join(keep_dir, "tracer.f32"))
+        with open(os.path.join(keep_dir, "meta.json"), "w") as f:
+            json.dump({"generator": "oracle/gen_golden/glsl_exec/random_scenes.py", "random_scene": d, "step": 1, "traced_width": W, "traced_height": H,
+                       "samples": [H, W], "camera": {k: [float(x) for x in v] for k, v in cam.items()}}, f, indent=1)
+    shutil.rmtree(dump, ignore_errors=True)
+    return int(diff.sum()), kinds
+
+
+def main():
+    first, end = int(sys.argv[1]), int(sys.argv[2])
+    keep = int(sys.argv[sys.argv.index("--keep") + 1]) if "--keep" in sys.argv else 0
+    bad = []
+    for k, seed in enumerate(range(first, end)):
+        keep_dir = os.path.join(REPO, "tests", "golden", "glsl_exec", "random_%d" % seed) if k < keep else None
+        n, kinds = run_seed(seed, keep_dir)
+        print("seed %d: %d of %d pixels differ (%d different primary hits)" % (seed, n, W * H, kinds), flush=True)
+        if n:
+            bad.append(seed)
+    print("seeds %d..%d: %d scenes differ %s" % (first, end - 1, len(bad), bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -61,6 +61,7 @@ function parseArgs(argv) {
         else if (k === '--drag') a.drag = argv[++i].split(',').map(Number);
         else if (k === '--trackball') a.trackball = argv[++i].split(',');
         else if (k === '--set') { const [n, v] = argv[++i].split('='); a.sets[n] = v; }
+        else if (k === '--scene-js') a.sceneJs = argv[++i];     // a file with another `function generateScene(meshes)`, written against the reference's classes
         else if (k === '--dump-glsl') a.dumpGlsl = argv[++i];   // directory OUTSIDE the repository: shader sources + texture payloads for oracle/gen_golden/glsl_exec
         else throw new Error('unknown arg ' + k);
     }
@@ -207,6 +208,11 @@ runRef('js/' + args.script, (src) => {
             })();`);
         usedSets.extra_mesh = args.extraObj + ' scale ' + args.extraScale + ' translate ' + args.extraTranslate.join(',') +
                               ' (indices rebased by the harness)';
+    }
+    if (args.sceneJs) {
+        // a later declaration of the same function name replaces the earlier one for the whole script (hoisting)
+        src = src + '\n' + fs.readFileSync(args.sceneJs, 'utf8') + '\n';
+        usedSets.scene_js = path.basename(args.sceneJs);
     }
     return src;
 });

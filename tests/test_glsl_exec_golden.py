@@ -17,11 +17,23 @@ import pytest
 from helpers import make_flat, model
 from oracle import oracle
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glsl_exec")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.join(REPO, "tests", "golden", "glsl_exec")
 NAMES = sorted(d for d in os.listdir(ROOT) if os.path.exists(os.path.join(ROOT, d, "meta.json")))
 
 
 def _scene(meta):
+    if "random_scene" in meta:
+        # a random scene (oracle/gen_golden/glsl_exec/random_scenes.py): the description realised on the Python twin of the scene
+        # classes, with the camera uniforms the reference computed for it
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("glsl_exec_random_scenes", os.path.join(REPO, "oracle", "gen_golden", "glsl_exec", "random_scenes.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        from ray_tracer_amd import abi
+        d = meta["random_scene"]
+        cam = {k: np.array(v, np.float32) for k, v in meta["camera"].items()}
+        return abi.FlatScene(mod.py_scene(d), abi.default_config(meta["traced_width"], meta["traced_height"], depth=d["depth"]), cam)
     kw = dict(meta["make_flat"])
     for k in ("mesh_material",):
         if kw.get(k) is not None:
@@ -35,6 +47,8 @@ def _scene(meta):
 def test_fixture_set_is_complete():
     assert len(NAMES) >= 7
     kinds = [json.load(open(os.path.join(ROOT, n, "meta.json"))) for n in NAMES]
+    assert sum("random_scene" in m for m in kinds) >= 4                             # scenes nobody tuned, through the reference's own classes
+    kinds = [m for m in kinds if "make_flat" in m]
     assert sum("canvas" in m for m in kinds) >= 3                                  # Ward, Reinhard and the odd-N present loop
     assert {m["make_flat"].get("ss", 1) for m in kinds} >= {1, 2, 3}
     assert max(m["make_flat"]["depth"] for m in kinds) >= 5
