@@ -12,7 +12,7 @@ transformations here are purely syntactic:
   * `T name[N]` becomes `garray<T, N> name` (out-of-range accesses are dropped, as the oracle assumes);
   * scalar declarations without an initialiser get `= 0` (vector and struct types zero themselves);
   * the three swizzles the shader uses become member calls.
-Usage: glsl2cpp.py DUMP_DIR OUT.f32 [--step 4]   (writes OUT.f32: float32 [ceil(H/step), ceil(W/step), 3], rows bottom-up)
+Usage: glsl2cpp.py DUMP_DIR OUT.f32 [--step 4] [--jobs N]   (N processes share the rows; writes OUT.f32: float32 [ceil(H/step), ceil(W/step), 3], rows bottom-up)
        glsl2cpp.py DUMP_DIR OUT.rgba8 --present FRAME.rgba8 LBAR SF
            the reference's present shader (js/8-kd_tree.js:85-143) over an RGBA8 render target of (W*S) x (H*S) bytes*4 with the
            two tone uniforms given as float32 values; writes the canvas, W x H x 4 bytes (float -> byte as the oracle does:
@@ -21,6 +21,7 @@ Usage: glsl2cpp.py DUMP_DIR OUT.f32 [--step 4]   (writes OUT.f32: float32 [ceil(
 import json
 import os
 import re
+import shutil
 import struct
 import subprocess
 import sys
@@ -238,7 +239,9 @@ int main(int argc, char **argv) {
     const vec3 r00(%(r00)s), r01(%(r01)s), r10(%(r10)s), r11(%(r11)s);
     FILE *out = fopen(argv[1], "wb");
     if (!out) { perror(argv[1]); return 1; }
-    for (int y = 0; y < H; y += step)
+    // optional row range (lattice rows y0 <= y < y1): several processes share a large frame
+    const int y0 = argc > 3 ? atoi(argv[2]) : 0, y1 = argc > 3 ? atoi(argv[3]) : H;
+    for (int y = y0; y < y1 && y < H; y += step)
         for (int x = 0; x < W; x += step) {
             reset_globals();
             set_uniforms();
@@ -262,7 +265,22 @@ int main(int argc, char **argv) {
     with open(src_path, "w") as f:
         f.write(cpp)
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused", "-o", exe, src_path])
-    subprocess.check_call([exe, out])
+    jobs = int(sys.argv[sys.argv.index("--jobs") + 1]) if "--jobs" in sys.argv else 1
+    if jobs <= 1:
+        subprocess.check_call([exe, out])
+    else:
+        # row slices that start on lattice rows, one process each, outputs joined in order
+        n_rows = (H + step - 1) // step
+        cuts = [((n_rows * k) // jobs) * step for k in range(jobs)] + [H]
+        procs = [subprocess.Popen([exe, "%s.part%d" % (out, k), str(cuts[k]), str(cuts[k + 1])]) for k in range(jobs)]
+        for pr in procs:
+            if pr.wait() != 0:
+                raise SystemExit("a slice of the frame failed")
+        with open(out, "wb") as f:
+            for k in range(jobs):
+                with open("%s.part%d" % (out, k), "rb") as g:
+                    shutil.copyfileobj(g, f)
+                os.remove("%s.part%d" % (out, k))
     print("wrote", out, "(%d x %d samples of the %d x %d frame)" % ((W + step - 1) // step, (H + step - 1) // step, W, H))
 
 

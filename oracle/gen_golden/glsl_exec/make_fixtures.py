@@ -44,6 +44,16 @@ CONFIGS = {
     "c2_res4_depth1_1920x1080": (["--script", "8-kd_tree.js", "--model", "models/bun_zipper_res4.ply", "--width", "1920", "--height", "1080",
                                   "--time", "7.5"], 12, False,
                                  dict(model_name="bun_zipper_res4.ply", width=1920, height=1080, depth=1, time=7.5)),
+    # the benchmarked frame (bench.py, benchmark configuration 3): full bunny + teapot, reflective and transmissive, depth 5, 4K
+    "c3_bunny_teapot_depth5_3840x2160": (["--script", "8-kd_tree.js", "--model", "models/bun_zipper.ply", "--width", "3840", "--height", "2160",
+                                          "--depth", "5", "--mesh-material", ",".join(str(v) for v in MM), "--extra-obj", "models/teapot.obj",
+                                          "--extra-scale", "60", "--extra-translate", "50,75,10"], 12, False,
+                                         dict(model_name="bun_zipper.ply", width=3840, height=2160, depth=5, time=0.0, mesh_material=MM,
+                                              extra_mesh=TEAPOT)),
+    # benchmark configuration 5's scene at one instant: project.js with its triangles switched on, full bunny, depth 4, 4K
+    "c5_project_triangles_depth4_3840x2160": (["--script", "project.js", "--model", "models/bun_zipper.ply", "--set", "RENDER_TRIANGLES=true",
+                                               "--ss", "1", "--width", "3840", "--height", "2160", "--time", "1.5"], 12, False,
+                                              dict(model_name="bun_zipper.ply", width=3840, height=2160, depth=4, time=1.5)),
     "project_ss2_ward_160x120": (["--script", "project.js", "--width", "160", "--height", "120", "--time", "2.25"], 1, True,
                                  dict(model_name="bun_zipper_res3.ply", width=160, height=120, depth=4, ss=2, time=2.25, render_triangles=0)),
     "tone7_ss2_reinhard_160x120": (["--script", "7-tone_reproduction.js", "--width", "160", "--height", "120",

@@ -45,7 +45,7 @@ def _scene(meta):
 
 
 def test_fixture_set_is_complete():
-    assert len(NAMES) >= 7
+    assert len(NAMES) >= 13
     kinds = [json.load(open(os.path.join(ROOT, n, "meta.json"))) for n in NAMES]
     assert sum("random_scene" in m for m in kinds) >= 4                             # scenes nobody tuned, through the reference's own classes
     kinds = [m for m in kinds if "make_flat" in m]
