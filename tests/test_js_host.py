@@ -224,6 +224,23 @@ def test_js_animation_same_frames_with_either_builder():
     assert one["last_canvas_sha256"] == dev["last_canvas_sha256"]
 
 
+@needs_node
+@pytest.mark.gpu
+def test_js_frames_sharded_over_worker_processes_equal_one_process():
+    """examples/animate_sharded.js: the animated job with frame k rendered by Node process k mod N (one process per GPU; here
+    three processes share the one GPU). Every frame's canvas must be the one a single process renders, and the frame
+    sequence must move (the light and the mesh do)."""
+    args = [os.path.join(JS, "examples", "animate_sharded.js"), "--width", "320", "--height", "240", "--depth", "3",
+            "--model", "models/bun_zipper_res4.ply", "--frames", "7", "--hash", "all"]
+    one = run_node(args + ["--gpus", "1"])
+    three = run_node(args + ["--gpus", "3", "--devices", "0,0,0"])
+    assert three["gpus"] == 3 and len(three["frame_sha256"]) == 7
+    assert three["frame_sha256"] == one["frame_sha256"]
+    assert len(set(one["frame_sha256"])) == 7
+    host = run_node(args + ["--gpus", "2", "--devices", "0,0", "--kd-builder", "host"])
+    assert host["frame_sha256"] == one["frame_sha256"]
+
+
 def _dragged_flat(m, width=640, height=480, depth=3):
     """The scene of the drag fixture after the drag, built with the Python scene twin: the mesh translated by the
     differences of the recorded positions (UI.mouseMove / mouseUp translate by newPosition - oldPosition,
