@@ -136,20 +136,39 @@ function makeRayTracer(G, THREE, api) {
             if (G.STATIC_GEOMETRY && this.geometryUpdatedOnce) return;
             const interval = G.KD_REBUILD_INTERVAL === undefined ? 0.30 : G.KD_REBUILD_INTERVAL;
             const gv = G.g_verts, gf = G.g_faces;
-            const verts = new Float64Array(gv.length * 3);
-            for (let i = 0; i < gv.length; i++) { verts[3 * i] = gv[i].x; verts[3 * i + 1] = gv[i].y; verts[3 * i + 2] = gv[i].z; }
-            const faces = new Uint32Array(gf.length * 3), mats = new Uint32Array(gf.length * 2);
-            for (let i = 0; i < gf.length; i++) {
-                const f = gf[i];
-                faces[3 * i] = f.indices[0]; faces[3 * i + 1] = f.indices[1]; faces[3 * i + 2] = f.indices[2];
-                const m = f.getMaterial();
-                if (!m) throw new Error('RayTracer: face ' + i + ' has no material');
-                mats[2 * i] = m.getType(); mats[2 * i + 1] = m.getId();
-            }
-            const same = (a, b) => { if (!b || a.length !== b.length) return false; for (let i = 0; i < a.length; i++) if (a[i] !== b[i]) return false; return true; };
             const k = this._meshKey;
-            const sameFaces = !!k && same(faces, k.faces) && same(mats, k.mats) && verts.length === k.verts.length;
-            const sameVerts = sameFaces && same(verts, k.verts);
+            // vertices: packed for the addon and compared with the last frame's in the same pass
+            const verts = new Float64Array(gv.length * 3);
+            const kv = k && k.verts.length === verts.length ? k.verts : null;
+            let sameVerts = kv !== null;
+            for (let i = 0, j = 0; i < gv.length; i++, j += 3) {
+                const v = gv[i], x = v.x, y = v.y, z = v.z;
+                verts[j] = x; verts[j + 1] = y; verts[j + 2] = z;
+                if (sameVerts && (kv[j] !== x || kv[j + 1] !== y || kv[j + 2] !== z)) sameVerts = false;   // (NaN counts as changed)
+            }
+            // faces and their materials: compared with the arrays of the last frame where they stand; only a frame that
+            // finds a difference (or the first one) packs new arrays
+            let faces = k ? k.faces : null, mats = k ? k.mats : null;
+            let sameFaces = !!k && faces.length === gf.length * 3 && !!kv;
+            for (let i = 0; sameFaces && i < gf.length; i++) {
+                const f = gf[i], ix = f.indices, m = f.getMaterial();
+                if (!m) throw new Error('RayTracer: face ' + i + ' has no material');
+                if (faces[3 * i] !== ix[0] || faces[3 * i + 1] !== ix[1] || faces[3 * i + 2] !== ix[2] ||
+                    mats[2 * i] !== m.getType() || mats[2 * i + 1] !== m.getId()) sameFaces = false;
+            }
+            if (!sameFaces) {
+                faces = new Uint32Array(gf.length * 3);
+                mats = new Uint32Array(gf.length * 2);
+                for (let i = 0; i < gf.length; i++) {
+                    const f = gf[i];
+                    faces[3 * i] = f.indices[0]; faces[3 * i + 1] = f.indices[1]; faces[3 * i + 2] = f.indices[2];
+                    const m = f.getMaterial();
+                    if (!m) throw new Error('RayTracer: face ' + i + ' has no material');
+                    mats[2 * i] = m.getType(); mats[2 * i + 1] = m.getId();
+                }
+            }
+            sameVerts = sameFaces && sameVerts;
+            const same = (a, b) => { if (!b || a.length !== b.length) return false; for (let i = 0; i < a.length; i++) if (a[i] !== b[i]) return false; return true; };
             const useTree = G.USE_KD_TREE && gf.length > 0;
             const rebuildDue = useTree && (this.startTime == 0 || time - this.startTime >= interval);
             const build = () => (G.KD_BUILDER === 'device' ? addon.buildKdTreeDevice : addon.buildKdTree)(this.ctx);

@@ -134,8 +134,15 @@ function makeSceneAPI(G, THREE) {
         // the global arrays hold the same Vector3 / Triangle objects, so a splice of equal length changes nothing
         // unless the mesh was edited; kept because callers may rely on it after editing verts/faces
         replaceInGlobal() {
-            G.g_faces.splice(this.startFaceIndex, this.facesLength, ...this.faces);
-            G.g_verts.splice(this.startVertIndex, this.vertsLength, ...this.verts);
+            // (a splice of 10^5 spread arguments per transform call costs more than the transform itself: skipped when the
+            // global arrays already hold exactly these objects in these places, which is the case unless the mesh was edited)
+            const holds = (glob, start, oldLength, mine) => {
+                if (oldLength !== mine.length) return false;
+                for (let i = 0; i < mine.length; i++) if (glob[start + i] !== mine[i]) return false;
+                return true;
+            };
+            if (!holds(G.g_faces, this.startFaceIndex, this.facesLength, this.faces)) G.g_faces.splice(this.startFaceIndex, this.facesLength, ...this.faces);
+            if (!holds(G.g_verts, this.startVertIndex, this.vertsLength, this.verts)) G.g_verts.splice(this.startVertIndex, this.vertsLength, ...this.verts);
             this.facesLength = this.faces.length;
             this.vertsLength = this.verts.length;
             G.g_geometryVersion = (G.g_geometryVersion || 0) + 1;
