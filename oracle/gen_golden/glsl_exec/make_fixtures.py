@@ -54,6 +54,11 @@ CONFIGS = {
     "c5_project_triangles_depth4_3840x2160": (["--script", "project.js", "--model", "models/bun_zipper.ply", "--set", "RENDER_TRIANGLES=true",
                                                "--ss", "1", "--width", "3840", "--height", "2160", "--time", "1.5"], 12, False,
                                               dict(model_name="bun_zipper.ply", width=3840, height=2160, depth=4, time=1.5)),
+    # the mesh dragged with the reference's own UI between two ticks 0.1 s apart: the second frame reads the moved vertices
+    # through the tree and root box of the first (js/8-kd_tree.js:2459-2533: vertices every frame, tree at most every 0.30 s)
+    "k8_res4_dragged_stale_tree_640x480": (["--script", "8-kd_tree.js", "--model", "models/bun_zipper_res4.ply", "--depth", "3", "--time", "1.0",
+                                            "--mesh-material", ",".join(str(v) for v in MM), "--drag", "330,40,335,120,330,200", "--drag-dt", "0.1"], 2, False,
+                                           dict(model_name="bun_zipper_res4.ply", width=640, height=480, depth=3, time=1.1, mesh_material=MM)),
     "project_ss2_ward_160x120": (["--script", "project.js", "--width", "160", "--height", "120", "--time", "2.25"], 1, True,
                                  dict(model_name="bun_zipper_res3.ply", width=160, height=120, depth=4, ss=2, time=2.25, render_triangles=0)),
     "tone7_ss2_reinhard_160x120": (["--script", "7-tone_reproduction.js", "--width", "160", "--height", "120",
@@ -87,6 +92,12 @@ def main():
         meta = {"generator": "oracle/gen_golden/glsl_exec/make_fixtures.py", "ref_capture_args": args, "step": step,
                 "traced_width": W, "traced_height": H, "samples": [(H + step - 1) // step, (W + step - 1) // step],
                 "make_flat": scene_kw}
+        if "--drag" in args:
+            with open(os.path.join(dump, "manifest", "manifest.json")) as f:
+                dr = json.load(f)["drag"]
+            assert dr["moving"] and dr["selected_index"] >= 0, "the drag did not grab the mesh"
+            meta["drag"] = {k: dr[k] for k in ("selected_index", "old_position", "positions", "dt", "mouse")}
+            meta["tree"] = "of the first tick (vertices before the drag)"
         if do_present:
             rgb = np.fromfile(tracer, np.float32).reshape(H, W, 3)
             c = np.where(np.isnan(rgb), 0.0, np.clip(rgb, 0.0, 1.0)).astype(np.float32)

@@ -40,7 +40,7 @@ const REF = process.env.RT_REFERENCE || '/root/reference';
 function parseArgs(argv) {
     const a = { script: '8-kd_tree.js', width: 640, height: 480, time: 0, sets: {}, fullArrays: false,
                 pixelPattern: 'lcg', out: null, ticks: 1,
-                meshMaterial: null, extraObj: null, extraScale: 1, extraTranslate: [0, 0, 0], drag: null, trackball: null };
+                meshMaterial: null, extraObj: null, extraScale: 1, extraTranslate: [0, 0, 0], drag: null, dragDt: 0.5, trackball: null };
     for (let i = 2; i < argv.length; i++) {
         const k = argv[i];
         if (k === '--script') a.script = argv[++i];
@@ -59,6 +59,7 @@ function parseArgs(argv) {
         else if (k === '--extra-scale') a.extraScale = +argv[++i];
         else if (k === '--extra-translate') a.extraTranslate = argv[++i].split(',').map(Number);
         else if (k === '--drag') a.drag = argv[++i].split(',').map(Number);
+        else if (k === '--drag-dt') a.dragDt = +argv[++i];   // seconds between the first tick and the tick after the drag (default 0.5)
         else if (k === '--trackball') a.trackball = argv[++i].split(',');
         else if (k === '--set') { const [n, v] = argv[++i].split('='); a.sets[n] = v; }
         else if (k === '--scene-js') a.sceneJs = argv[++i];     // a file with another `function generateScene(meshes)`, written against the reference's classes
@@ -257,8 +258,11 @@ setImmediate(() => {
             return rec;
         })()`, sandbox);
         dragRecord.mouse = d;
-        // the frame after the drag; time advanced past the rebuild throttle (js/8-kd_tree.js:2495) so the tree follows
-        vm.runInContext('tick(' + (args.time + 0.5) + ')', sandbox);
+        // the frame after the drag; by default time has advanced past the rebuild throttle (js/8-kd_tree.js:2495) so the tree
+        // follows; with --drag-dt under 0.30 (and a first tick at a time other than 0) the reference renders the moved
+        // vertices through the tree of the first tick
+        dragRecord.dt = args.dragDt;
+        vm.runInContext('tick(' + (args.time + args.dragDt) + ')', sandbox);
     }
 
     let trackballRecord = null;
