@@ -59,6 +59,20 @@ CONFIGS = {
     "k8_res4_dragged_stale_tree_640x480": (["--script", "8-kd_tree.js", "--model", "models/bun_zipper_res4.ply", "--depth", "3", "--time", "1.0",
                                             "--mesh-material", ",".join(str(v) for v in MM), "--drag", "330,40,335,120,330,200", "--drag-dt", "0.1"], 2, False,
                                            dict(model_name="bun_zipper_res4.ply", width=640, height=480, depth=3, time=1.1, mesh_material=MM)),
+    # the camera after a pan, a rotation and a wheel zoom with the reference's own TrackballControls (the steps of the fixture
+    # k8_res4_trackball_640x480): corner rays no longer symmetric, camera off the origin; the camera uniforms travel in meta.json
+    "k8_res4_trackball_depth3_640x480": (["--script", "8-kd_tree.js", "--model", "models/bun_zipper_res4.ply", "--depth", "3",
+                                          "--mesh-material", ",".join(str(v) for v in MM),
+                                          "--trackball", "down:2:20:20,move:24:22,tick,up:24:22,tick,tick,down:0:20:20,move:22:21,tick,move:23:23,tick,up:23:23,tick,tick,wheel:-100,tick,tick"],
+                                         4, False, dict(model_name="bun_zipper_res4.ply", width=640, height=480, depth=3, time="trackball", mesh_material=MM)),
+    # the shader's brute-force loop over all faces (USE_KD_TREE false)
+    "k8_res4_no_kdtree_depth2_640x480": (["--script", "8-kd_tree.js", "--model", "models/bun_zipper_res4.ply", "--depth", "2", "--set", "USE_KD_TREE=false",
+                                          "--mesh-material", ",".join(str(v) for v in MM)], 8, False,
+                                         dict(model_name="bun_zipper_res4.ply", width=640, height=480, depth=2, time=0.0, mesh_material=MM, use_kd_tree=0)),
+    # a shallow tree: most leaves hold more than four faces and keep only the first four (js/8-kd_tree.js:1728-1730)
+    "k8_res3_kd_depth8_depth3_640x480": (["--script", "8-kd_tree.js", "--model", "models/bun_zipper_res3.ply", "--depth", "3", "--set", "MAX_KD_TREE_DEPTH=8",
+                                          "--mesh-material", ",".join(str(v) for v in MM)], 4, False,
+                                         dict(model_name="bun_zipper_res3.ply", width=640, height=480, depth=3, time=0.0, mesh_material=MM, max_kd_depth=8)),
     "project_ss2_ward_160x120": (["--script", "project.js", "--width", "160", "--height", "120", "--time", "2.25"], 1, True,
                                  dict(model_name="bun_zipper_res3.ply", width=160, height=120, depth=4, ss=2, time=2.25, render_triangles=0)),
     "tone7_ss2_reinhard_160x120": (["--script", "7-tone_reproduction.js", "--width", "160", "--height", "120",
@@ -92,6 +106,14 @@ def main():
         meta = {"generator": "oracle/gen_golden/glsl_exec/make_fixtures.py", "ref_capture_args": args, "step": step,
                 "traced_width": W, "traced_height": H, "samples": [(H + step - 1) // step, (W + step - 1) // step],
                 "make_flat": scene_kw}
+        if "--trackball" in args:
+            with open(os.path.join(dump, "dump.json")) as f:
+                last = {}
+                for un in json.load(f)["uniforms"]:
+                    last[un["name"]] = un["value"]
+            meta["camera"] = {k: last[k] for k in ("cameraPos", "ray00", "ray01", "ray10", "ray11")}
+            with open(os.path.join(dump, "manifest", "manifest.json")) as f:
+                meta["make_flat"]["time"] = json.load(f)["trackball"]["last_time"]   # the light follows the last tick's time
         if "--drag" in args:
             with open(os.path.join(dump, "manifest", "manifest.json")) as f:
                 dr = json.load(f)["drag"]

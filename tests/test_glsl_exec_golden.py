@@ -43,7 +43,15 @@ def _scene(meta):
     if kw.get("extra_mesh") is not None:
         n, s, t = kw["extra_mesh"]
         kw["extra_mesh"] = (model(n), s, tuple(t))
-    return make_flat(**kw)
+    flat = make_flat(**kw)
+    if "camera" in meta:   # a camera the reference's controls moved: its uniforms as the reference handed them to WebGL
+        from ray_tracer_amd import abi, scene
+        cam = {k: np.array(v, np.float32) for k, v in meta["camera"].items()}
+        assert not np.array_equal(cam["cameraPos"], np.zeros(3, np.float32))
+        sc = scene.default_scene(model(kw["model_name"]), mesh_material=kw.get("mesh_material"))
+        scene.animate_light(sc, kw["time"])
+        flat = abi.FlatScene(sc, flat.cfg, cam)
+    return flat
 
 
 def _dragged(meta):
@@ -68,7 +76,7 @@ def _dragged(meta):
 
 
 def test_fixture_set_is_complete():
-    assert len(NAMES) >= 14
+    assert len(NAMES) >= 17
     kinds = [json.load(open(os.path.join(ROOT, n, "meta.json"))) for n in NAMES]
     assert sum("random_scene" in m for m in kinds) >= 4                             # scenes nobody tuned, through the reference's own classes
     assert sum("drag" in m for m in kinds) >= 1                                      # moved vertices under a stale tree
