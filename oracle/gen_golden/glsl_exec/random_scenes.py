@@ -11,7 +11,8 @@ transform, recursion depth 2 .. 5) and realised twice from one description:
   * as Python against ray-tracer_amd/scene.py (the twin the tests use), rendered by the CPU oracle with the camera
     uniforms the reference produced.
 The two float32 frames must be equal bit for bit. Usage:
-    python oracle/gen_golden/glsl_exec/random_scenes.py FIRST_SEED END_SEED [--keep N]
+    python oracle/gen_golden/glsl_exec/random_scenes.py FIRST_SEED END_SEED [--keep N] [--ch6]
+--ch6 sends the scenes (without the mesh) through checkpoint 6's page script and its GLSL ES 1.00 shader text instead.
 --keep N stores the first N scenes as fixtures under tests/golden/glsl_exec/ (description + pixels; never the shader text),
 which tests/test_glsl_exec_golden.py picks up. Everything else happens under /tmp.
 """
@@ -76,7 +77,7 @@ def describe(seed):
     return d
 
 
-def js_scene(d):
+def js_scene(d, with_mesh=True):
     """generateScene() for the reference's page script (its classes, its id counters, its globals)."""
     num = lambda v: repr(float(v))
     vec = lambda v: "new THREE.Vector3(%s)" % ", ".join(num(x) for x in v)
@@ -88,7 +89,8 @@ def js_scene(d):
         L.append("    var m%d = new %s(%s++, %s, %s);" % (i, m["type"], counter[m["type"]], ", ".join(num(x) for x in m["k"]),
                                                        ", ".join(vec(c) for c in m["colors"])))
         L.append("    materials.push(m%d);" % i)
-    L += ["    g_verts = [];", "    g_faces = [];"]
+    if with_mesh:
+        L += ["    g_verts = [];", "    g_faces = [];"]
 
     def place(name, o):
         if o["scale"] is not None:
@@ -101,8 +103,9 @@ def js_scene(d):
     for i, o in enumerate(d["objects"]):
         L.append("    var o%d = new %s(nextObjectId++);" % (i, o["kind"]))
         place("o%d" % i, o)
-    L.append("    var mesh = new Mesh(nextObjectId++, meshes[MODEL_FILE_NAME].verts, meshes[MODEL_FILE_NAME].faces);")
-    place("mesh", d["mesh"])
+    if with_mesh:
+        L.append("    var mesh = new Mesh(nextObjectId++, meshes[MODEL_FILE_NAME].verts, meshes[MODEL_FILE_NAME].faces);")
+        place("mesh", d["mesh"])
     # the camera: only its place; the reference's controls aim it (TrackballControls.update looks at its target)
     L.append("    camera.position.set(%s);" % ", ".join(num(x) for x in d["camera_pos"]))
     L.append("    return { objects: objects, materials: materials, lights: lights, ambientLight: %s, bgColor: %s };" % (vec(d["ambient"]), vec(d["bg"])))
@@ -110,7 +113,7 @@ def js_scene(d):
     return "\n".join(L) + "\n"
 
 
-def py_scene(d):
+def py_scene(d, with_mesh=True, animate=True):
     """The same description on the Python twin of the scene classes."""
     from ray_tracer_amd import scene
     from ray_tracer_amd.three_f32 import Euler, Vector3 as V
@@ -142,11 +145,13 @@ def py_scene(d):
         sc.objects.append(o)
     for spec in d["objects"]:
         place(getattr(scene, spec["kind"])(nid("object")), spec)
-    v, f = scene.load_ply(model(MODEL))
-    place(scene.Mesh(nid("object"), v, f, sc.meshes), d["mesh"])
+    if with_mesh:
+        v, f = scene.load_ply(model(MODEL))
+        place(scene.Mesh(nid("object"), v, f, sc.meshes), d["mesh"])
     sc.ambientLight = V(*d["ambient"])
     sc.bgColor = V(*d["bg"])
-    scene.animate_light(sc, d["time"])
+    if animate:
+        scene.animate_light(sc, d["time"])
     return sc
 
 
@@ -160,38 +165,42 @@ def camera_of(dump):
     return {k: np.array(last[k], np.float32) for k in ("cameraPos", "ray00", "ray01", "ray10", "ray11")}
 
 
-def oracle_frame(d, cam):
+def oracle_frame(d, cam, ch6=False):
     from oracle import oracle
     from ray_tracer_amd import abi
-    flat = abi.FlatScene(py_scene(d), abi.default_config(W, H, depth=d["depth"]), cam)
+    if ch6:   # checkpoint 6: no mesh in the scene, INFINITY 100000.1 (js/6-transmission.js:22), the light stays where the scene puts it
+        flat = abi.FlatScene(py_scene(d, with_mesh=False, animate=False), abi.default_config(W, H, depth=d["depth"], infinity=100000.1), cam)
+    else:
+        flat = abi.FlatScene(py_scene(d), abi.default_config(W, H, depth=d["depth"]), cam)
     o = oracle.OracleRenderer(flat)
     rgb, rgba, ids, cn = o.trace()
     return rgb, ids, flat
 
 
-def run_seed(seed, keep_dir=None):
+def run_seed(seed, keep_dir=None, ch6=False):
     d = describe(seed)
     dump = os.path.join(SCRATCH, "s%d" % seed)
     shutil.rmtree(dump, ignore_errors=True)
     os.makedirs(dump)
     with open(os.path.join(dump, "scene.js"), "w") as f:
-        f.write(js_scene(d))
-    subprocess.check_call(["node", os.path.join(REPO, "oracle", "gen_golden", "ref_capture.js"), "--script", "8-kd_tree.js",
-                           "--model", "models/" + MODEL, "--width", str(W), "--height", str(H), "--depth", str(d["depth"]),
+        f.write(js_scene(d, with_mesh=not ch6))
+    script = ["--script", "6-transmission.js"] if ch6 else ["--script", "8-kd_tree.js", "--model", "models/" + MODEL]
+    subprocess.check_call(["node", os.path.join(REPO, "oracle", "gen_golden", "ref_capture.js")] + script +
+                          ["--width", str(W), "--height", str(H), "--depth", str(d["depth"]),
                            "--time", repr(d["time"]), "--scene-js", os.path.join(dump, "scene.js"),
                            "--out", os.path.join(dump, "manifest"), "--dump-glsl", dump], stdout=subprocess.DEVNULL)
     out = os.path.join(dump, "tracer.f32")
     subprocess.check_call([sys.executable, os.path.join(HERE, "glsl2cpp.py"), dump, out, "--step", "1"], stdout=subprocess.DEVNULL)
     want = np.fromfile(out, np.float32).reshape(H, W, 3)
     cam = camera_of(dump)
-    got, ids, flat = oracle_frame(d, cam)
+    got, ids, flat = oracle_frame(d, cam, ch6)
     diff = (got.view(np.uint32) != want.view(np.uint32)).any(-1)
     kinds = len(np.unique(ids))
     if keep_dir and not diff.any():
         os.makedirs(keep_dir, exist_ok=True)
         want.tofile(os.path.join(keep_dir, "tracer.f32"))
         with open(os.path.join(keep_dir, "meta.json"), "w") as f:
-            json.dump({"generator": "oracle/gen_golden/glsl_exec/random_scenes.py", "random_scene": d, "step": 1, "traced_width": W, "traced_height": H,
+            json.dump({"generator": "oracle/gen_golden/glsl_exec/random_scenes.py", "random_scene": d, "checkpoint6": ch6, "step": 1, "traced_width": W, "traced_height": H,
                        "samples": [H, W], "camera": {k: [float(x) for x in v] for k, v in cam.items()}}, f, indent=1)
     shutil.rmtree(dump, ignore_errors=True)
     return int(diff.sum()), kinds
@@ -200,10 +209,11 @@ def run_seed(seed, keep_dir=None):
 def main():
     first, end = int(sys.argv[1]), int(sys.argv[2])
     keep = int(sys.argv[sys.argv.index("--keep") + 1]) if "--keep" in sys.argv else 0
+    ch6 = "--ch6" in sys.argv   # through js/6-transmission.js (GLSL ES 1.00 text, no mesh) instead of js/8-kd_tree.js
     bad = []
     for k, seed in enumerate(range(first, end)):
-        keep_dir = os.path.join(REPO, "tests", "golden", "glsl_exec", "random_%d" % seed) if k < keep else None
-        n, kinds = run_seed(seed, keep_dir)
+        keep_dir = os.path.join(REPO, "tests", "golden", "glsl_exec", "random_%s%d" % ("ch6_" if ch6 else "", seed)) if k < keep else None
+        n, kinds = run_seed(seed, keep_dir, ch6)
         print("seed %d: %d of %d pixels differ (%d different primary hits)" % (seed, n, W * H, kinds), flush=True)
         if n:
             bad.append(seed)

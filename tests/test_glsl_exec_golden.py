@@ -33,6 +33,9 @@ def _scene(meta):
         from ray_tracer_amd import abi
         d = meta["random_scene"]
         cam = {k: np.array(v, np.float32) for k, v in meta["camera"].items()}
+        if meta.get("checkpoint6"):   # through js/6-transmission.js: no mesh, INFINITY 100000.1, light 0 where the scene puts it
+            return abi.FlatScene(mod.py_scene(d, with_mesh=False, animate=False),
+                                 abi.default_config(meta["traced_width"], meta["traced_height"], depth=d["depth"], infinity=100000.1), cam)
         return abi.FlatScene(mod.py_scene(d), abi.default_config(meta["traced_width"], meta["traced_height"], depth=d["depth"]), cam)
     if "drag" in meta:
         return _dragged(meta)[0]
@@ -76,7 +79,7 @@ def _dragged(meta):
 
 
 def test_fixture_set_is_complete():
-    assert len(NAMES) >= 17
+    assert len(NAMES) >= 19
     kinds = [json.load(open(os.path.join(ROOT, n, "meta.json"))) for n in NAMES]
     assert sum("random_scene" in m for m in kinds) >= 4                             # scenes nobody tuned, through the reference's own classes
     assert sum("drag" in m for m in kinds) >= 1                                      # moved vertices under a stale tree
