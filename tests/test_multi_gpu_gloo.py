@@ -37,9 +37,14 @@ class OracleShard:
         from oracle import oracle
         self.ora = oracle.OracleRenderer(flat)
         self.rank, self.world = rank, world
+        # the library's tile order (rt_kernels.h: tile_coords): 8x8-pixel tiles numbered in blocks of 16 x 16 tiles, Z-order
+        # inside a block, the blocks row by row; the numbering runs over whole blocks, so tiles beyond the image edge exist
+        # in it and hold no pixels. Shard r owns tiles r, r + world, ... of that numbering.
         self.tx, self.ty = (W + 7) // 8, (H + 7) // 8
-        self.tiles = list(range(rank, self.tx * self.ty, world))
-        self.stride = ((self.tx * self.ty + world - 1) // world) * 256
+        self.bx, self.by = (self.tx + 15) // 16, (self.ty + 15) // 16
+        self.n_tiles = self.bx * self.by * 256
+        self.tiles = list(range(rank, self.n_tiles, world))
+        self.stride = ((self.n_tiles + world - 1) // world) * 256
         self.full = None
         self.frame = None
 
@@ -47,7 +52,9 @@ class OracleShard:
         _, self.full, _, _ = self.ora.trace(threads=2, want_float=False, want_ids=False)
 
     def _tile_pixels(self, t):
-        x0, y0 = (t % self.tx) * 8, (t // self.tx) * 8
+        even = lambda w: sum(((w >> (2 * k)) & 1) << k for k in range(4))   # bits 0, 2, 4, 6 -> a 4-bit number
+        block, w = t >> 8, t & 255
+        x0, y0 = ((block % self.bx) * 16 + even(w)) * 8, ((block // self.bx) * 16 + even(w >> 1)) * 8
         for ly in range(8):
             for lx in range(8):
                 yield ly * 8 + lx, x0 + lx, y0 + ly
@@ -74,7 +81,7 @@ class OracleShard:
         g = gathered.numpy()
         self.frame = np.zeros((H, W, 4), np.uint8)
         for r in range(world):
-            for k, t in enumerate(range(r, self.tx * self.ty, world)):
+            for k, t in enumerate(range(r, self.n_tiles, world)):
                 for lane, x, y in self._tile_pixels(t):
                     px = g[r * stride + k * 256 + lane * 4:r * stride + k * 256 + lane * 4 + 4]
                     if x < W and y < H:
@@ -175,6 +182,37 @@ def hip_worker(rank, world, port, out):
     out.put(res)
     comm.close()
     rt.close()
+
+
+@pytest.mark.gpu
+def test_cpu_stand_in_lays_its_shards_out_like_the_library():
+    """The CPU ranks of the gloo tests (OracleShard) number the tiles themselves; the job logic they exercise means
+    something only if that numbering is the library's: every rank's buffer must be, byte for byte, what
+    rt_device_shard_rgba8 hands out for the same shard of the same frame (ragged frame, three shards)."""
+    import ctypes as C
+    from ray_tracer_amd import abi
+    flat = make_flat("bun_zipper_res4.ply", W, H, depth=2, mesh_material=(0.7, 0.6, 0.7, 16, 0.3, 0.0, 0.0))
+    hip = C.CDLL("libamdhip64.so")
+    world = 3
+    for r in range(world):
+        cpu = OracleShard(flat, r, world)
+        cpu.trace()
+        want, stride = cpu.shard_bytes()
+        flat.cfg.shard_index, flat.cfg.shard_count = r, world
+        rt = abi.RayTracerHIP(flat.cfg)
+        rt.setScene(flat)
+        rt.trace()
+        p, nb = C.c_void_p(), C.c_size_t()
+        assert rt.L.rt_device_shard_rgba8(rt.ctx, C.byref(p), C.byref(nb)) == 0
+        got = np.zeros(nb.value, np.uint8)
+        assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), p, C.c_size_t(nb.value), 2) == 0
+        assert nb.value == 256 * len(cpu.tiles) and nb.value <= stride
+        assert np.array_equal(got, want.numpy()[:nb.value]), r
+        s_cpu, n_cpu = cpu.tone_partial()
+        s_gpu, n_gpu = rt.tonePartial()
+        assert n_gpu == n_cpu and abs(s_gpu - s_cpu) <= 1e-10 * abs(s_cpu)
+        rt.close()
+    flat.cfg.shard_index, flat.cfg.shard_count = 0, 1
 
 
 @pytest.mark.gpu
