@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build container only: ONE whole frame of a configuration of make_fixtures.py through the reference's executed shader
-text (every pixel, several processes) against the oracle's frame, float32 bit for bit. Nothing is stored but the verdict.
+text (every pixel, several processes) against the oracle's frame, float32 bit for bit. Nothing is stored but the outcome.
 Usage: python oracle/gen_golden/glsl_exec/whole_frame.py NAME [--jobs 8]     (NAME: a key of make_fixtures.CONFIGS)"""
 import os
 import shutil
