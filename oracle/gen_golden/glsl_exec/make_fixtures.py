@@ -135,6 +135,15 @@ def main():
                 acc += v
             Lbar = math.exp(acc)
             sf = ((1.219 + (500 * 0.5) ** 0.4) / (1.219 + Lbar ** 0.4)) ** 2.5
+            # ... and by the reference's own loop: the page script once more, its readPixels handed this very frame
+            again = os.path.join(dump, "manifest_tone")
+            subprocess.check_call(["node", os.path.join(REPO, "oracle", "gen_golden", "ref_capture.js")] + args +
+                                  ["--pixels", "file:" + fpath, "--out", again], stdout=subprocess.DEVNULL)
+            with open(os.path.join(again, "manifest.json")) as f:
+                ref_tone = json.load(f)
+            assert f32(ref_tone["Lbar"]) == f32(Lbar) and f32(ref_tone["sf"]) == f32(sf), (ref_tone["Lbar"], Lbar, ref_tone["sf"], sf)
+            Lbar, sf = ref_tone["Lbar"], ref_tone["sf"]
+            meta["tone_from"] = "the reference's own loop (js/8-kd_tree.js:2559-2569) over the executed frame"
             canvas = os.path.join(out, "canvas.rgba8")
             subprocess.check_call([sys.executable, os.path.join(HERE, "glsl2cpp.py"), dump, canvas, "--present", fpath, repr(f32(Lbar)), repr(f32(sf))])
             meta.update(Lbar_f32=f32(Lbar), sf_f32=f32(sf), canvas=[scene_kw["height"], scene_kw["width"]])

@@ -163,6 +163,12 @@ runRef('js/controls/TrackballControls.js');
 // synthetic frame for the log-luminance loop (js/8-kd_tree.js:2558-2569)
 readPixelsFill = (dst, w, h) => {
     if (args.pixelPattern === 'zero') { dst.fill(0); return; }
+    if (args.pixelPattern.startsWith('file:')) {   // a frame made elsewhere (the executed tracer shader's, quantised): RGBA8, rows bottom-up
+        const buf = fs.readFileSync(args.pixelPattern.slice(5));
+        if (buf.length !== dst.length) throw new Error('--pixels file: ' + buf.length + ' bytes, readPixels wants ' + dst.length);
+        dst.set(buf);
+        return;
+    }
     if (args.pixelPattern.startsWith('const:')) {
         const [r, g, b] = args.pixelPattern.slice(6).split(',').map(Number);
         for (let i = 0; i < dst.length; i += 4) { dst[i] = r; dst[i + 1] = g; dst[i + 2] = b; dst[i + 3] = 255; }
